@@ -1,0 +1,136 @@
+/*
+ * fl_oracle.h -- CPU restatement (plain C) of the line-search optimisers of the
+ * reference's source/NonlinearOptimization.f90 ("NO.f90").
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it,
+ * and only as the checker / reported CPU baseline.  The product (libFL.so,
+ * fortran-library_amd/csrc) never links, loads or calls it.
+ *
+ * Parity status: the reference ships no golden vectors for this path
+ * (test/test.f90 seeds from the wall clock) and cannot be built in this image
+ * without a hand-written stand-in for Intel's closed mkl_rci.f90 (NO.f90:15),
+ * so no reference build is made.  The restatement is pinned against the
+ * reference outputs recorded in BASELINE.md section 2 (final objective values
+ * and f / grad evaluation counts measured on the reference during the survey);
+ * see tests/test_oracle_pins.py.  Everything those numbers do not cover
+ * (numerical-Hessian branches = MKL djacobi) is "parity unpinned".
+ *
+ * Two summation modes:
+ *   FLO_SUM_SEQ  : every dot_product / objective sum runs left to right like
+ *                  the reference compiled without fast-math (NO.f90 uses the
+ *                  dot_product intrinsic everywhere, e.g. NO.f90:442, 591).
+ *   FLO_SUM_TREE : the same algorithm with every sum taken in the fixed
+ *                  reduction order of the HIP kernels (thread-strided partials,
+ *                  64-lane xor butterfly, waves left to right) so that the GPU
+ *                  result can be compared BIT FOR BIT.
+ */
+#ifndef FL_ORACLE_H
+#define FL_ORACLE_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* callbacks: the reference's (NO.f90:33-38, 1928-1937) plus a context pointer */
+typedef void (*flo_f_t)(double *fx, const double *x, int n, void *ctx);
+typedef void (*flo_fd_t)(double *g, const double *x, int n, void *ctx);
+typedef int (*flo_ffd_t)(double *fx, double *g, const double *x, int n, void *ctx);
+typedef int (*flo_fdd_t)(double *H, const double *x, int n, void *ctx);
+typedef void (*flo_c_t)(double *cx, const double *x, int m, int n, void *ctx);
+typedef void (*flo_cd_t)(double *cdx, const double *x, int m, int n, void *ctx);
+
+enum { FLO_SUM_SEQ = 0, FLO_SUM_TREE = 1 };
+/* thread-local: summation mode and GPU reduction geometry (threads per problem,
+ * elements per thread) used by FLO_SUM_TREE */
+void flo_set_sum_mode(int mode, int threads, int ept);
+double flo_dot(int n, const double *a, const double *b);
+double flo_tree_sum(int n, const double *term);
+
+enum { FLO_CONVERGED = 0, FLO_STEP_CONVERGED = 1, FLO_MAXIT = 2 };
+
+typedef struct {
+    /* optional arguments of the reference, all explicit (defaults: flo_defaults) */
+    int strong;       /* Strong         (default 1)     */
+    int maxit;        /* MaxIteration   (default 1000)  */
+    double precision; /* Precision      (default 1e-15) */
+    double minstep;   /* MinStepLength  (default 1e-15) */
+    double c1, c2;    /* WolfeConst1/2  (1e-4, 0.9; CG 0.45) */
+    double increment; /* Increment      (default 1.05)  */
+    int memory;       /* L-BFGS Memory  (default 10)    */
+    int exact_step;   /* BFGS ExactStep (default 20)    */
+    int method;       /* CG: 0 = DY, 1 = PR */
+    int clamp;        /* apply the fail-safe clamps of NO.f90:83-86 (1) or not (_basic, 0) */
+} flo_opts;
+
+typedef struct {
+    int status;  /* FLO_* */
+    int iters;   /* line searches performed */
+    int nf, ng;  /* f / grad evaluations (f_fd counts as one of each) */
+    double f;    /* objective at exit */
+    double gg;   /* g.g at exit */
+} flo_stats;
+
+void flo_defaults(flo_opts *o);
+
+/* line searchers: NO.f90:1286 (Wolfe), 1373 (Wolfe_fdwithf), 1462 (StrongWolfe),
+ * 1582 (StrongWolfe_fdwithf).  p is the direction; on exit x = x0 + a p. */
+void flo_wolfe(double c1, double c2, flo_f_t f, flo_fd_t fd, double *x, double *a, const double *p,
+               double *fx, double phid0, double *fdx, int n, double increment, void *ctx, flo_stats *st);
+void flo_strong_wolfe(double c1, double c2, flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, double *x, double *a,
+                      const double *p, double *fx, double phid0, double *fdx, int n, double increment,
+                      void *ctx, flo_stats *st);
+
+/* solvers: f_fd may be NULL ("absent") */
+void flo_steepest_descent(flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, double *x, int n, const flo_opts *o,
+                          void *ctx, flo_stats *st); /* NO.f90:55  */
+void flo_conjugate_gradient(flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, double *x, int n, const flo_opts *o,
+                            void *ctx, flo_stats *st); /* NO.f90:193 */
+void flo_lbfgs(flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, double *x, int n, const flo_opts *o, void *ctx,
+               flo_stats *st); /* NO.f90:398 */
+/* BFGS (NO.f90:632).  update_form 0 = as written (two dense matmuls, NO.f90:961),
+ * 1 = algebraically equal rank-2 form (what the HIP kernel computes). fdd may be NULL;
+ * exact_step > 0 without fdd uses an own central difference (MKL djacobi: parity unpinned). */
+void flo_bfgs(flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, flo_fdd_t fdd, double *x, int n, const flo_opts *o,
+              int update_form, void *ctx, flo_stats *st);
+/* AugmentedLagrangian (NO.f90:2005): solver 0 = BFGS, 1 = LBFGS, 2 = ConjugateGradient.
+ * lambda[m] in/out (reference: lambda0 copy), miu0 as given. outer_iters returns the
+ * number of outer iterations. */
+void flo_augmented_lagrangian(flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, flo_c_t c, flo_cd_t cd, double *x, int n,
+                              int m, int solver, double *lambda, double miu0, const flo_opts *o, void *ctx,
+                              flo_stats *st, int *outer_iters, double *cnorm2);
+
+/* dense helpers restated from LinearAlgebra.f90 (column-major) */
+int flo_dpotri_lower(double *A, int n); /* My_dpotri LA.f90:798 : dpotrf+dpotri 'L'; returns info */
+void flo_syL2U(double *A, int n);       /* dsyL2U LA.f90:260 */
+
+/* ---- built-in synthetic problems (fl_oracle_problems.c) ---- */
+enum { FLO_QUARTIC = 0, FLO_ROSENBROCK = 1, FLO_DIAGQUAD = 2 };
+typedef struct {
+    int kind;
+    const double *d, *b; /* DIAGQUAD data */
+    /* block-sphere constraints c_j = sum_{i in block j} x_i^2 - 1 (m blocks of n/m) */
+} flo_problem;
+void flo_prob_f(double *fx, const double *x, int n, void *ctx);
+void flo_prob_fd(double *g, const double *x, int n, void *ctx);
+int flo_prob_ffd(double *fx, double *g, const double *x, int n, void *ctx);
+int flo_prob_fdd(double *H, const double *x, int n, void *ctx);
+void flo_prob_c(double *cx, const double *x, int m, int n, void *ctx);
+void flo_prob_cd(double *cdx, const double *x, int m, int n, void *ctx);
+
+enum { FLO_SD = 0, FLO_CG = 1, FLO_LBFGS = 2, FLO_BFGS = 3 };
+/* batched driver, OpenMP over problems (one problem per thread, like the reference
+ * which is single-threaded per problem).  x[B][n] in/out, d/b [B][n] or NULL,
+ * outputs [B].  sum_mode/threads/ept select the summation order.  use_ffd: pass
+ * f_fd to the solver (the reference's "f_fd present").  Returns threads used. */
+int flo_solve_batch(int solver, int kind, int B, int n, double *x, const double *d, const double *b,
+                    const flo_opts *o, int use_ffd, int bfgs_form, int sum_mode, int threads, int ept,
+                    int nthreads, double *fout, int *iters, int *status, int *nf, int *ng, double *gg);
+int flo_auglag_batch(int solver, int kind, int B, int n, int m, double *x, const double *d, const double *b,
+                     double *lambda, double miu0, const flo_opts *o, int use_ffd, int sum_mode, int threads,
+                     int ept, int nthreads, double *fout, int *iters, int *outer, int *nf, int *ng,
+                     double *cnorm2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
