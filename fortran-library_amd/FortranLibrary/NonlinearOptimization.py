@@ -1,0 +1,166 @@
+"""Batched line-search optimisers on MI355X -- ctypes over libFL.so's C ABI.
+
+Names follow the reference module ``NonlinearOptimization``
+(/root/reference/source/NonlinearOptimization.f90): LBFGS (398), ConjugateGradient
+(193), SteepestDescent (55); keyword names and defaults are the reference's optional
+arguments (NO.f90:41-51).  Inputs are torch CUDA tensors (fp64, problem-major
+[batch, n]); x is updated in place like the reference's ``x`` (intent inout).
+torch is only the carrier of device memory and the stream -- all arithmetic runs in
+the HIP kernels.
+"""
+import ctypes as C
+
+from .basic import FL
+
+QUARTIC, ROSENBROCK, DIAGQUAD = 0, 1, 2
+CONVERGED, STEP_CONVERGED, MAXIT = 0, 1, 2
+SD, CG, LBFGS_ = 0, 1, 2
+OK = 0
+
+
+class Options(C.Structure):
+    """struct fl_options (include/fl_nlopt.h)."""
+    _fields_ = [("strong", C.c_int32), ("max_iteration", C.c_int32), ("precision", C.c_double),
+                ("min_step_length", C.c_double), ("wolfe_c1", C.c_double), ("wolfe_c2", C.c_double),
+                ("increment", C.c_double), ("memory", C.c_int32), ("cg_method", C.c_int32),
+                ("fused_f_fd", C.c_int32), ("clamp", C.c_int32)]
+
+
+_vp, _dp, _ip = C.c_void_p, C.c_void_p, C.c_void_p
+FL.fl_version.restype = C.c_int
+FL.fl_default_options.argtypes = [C.POINTER(Options), C.c_int]
+FL.fl_default_options.restype = None
+FL.fl_reduction_geometry.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+FL.fl_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+FL.fl_workspace_bytes.restype = C.c_size_t
+FL.fl_lbfgs_batched.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.POINTER(Options), _vp, C.c_size_t, _dp,
+                                _dp, _ip, _ip, _ip, _ip, _vp]
+_cg_sd = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.POINTER(Options), _dp, _dp, _ip, _ip, _ip, _ip, _vp]
+FL.fl_conjugate_gradient_batched.argtypes = _cg_sd
+FL.fl_steepest_descent_batched.argtypes = _cg_sd
+FL.fl_lbfgs_two_loop_batched.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _vp]
+FL.fl_synth_uniform.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_double, _dp, _vp]
+FL.fl_synth_diag_spectrum.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_double, _dp, _vp]
+
+
+class FLError(RuntimeError):
+    pass
+
+
+def _check(rc, what):
+    if rc != OK:
+        names = {-1: "FL_ERR_INVALID_ARGUMENT", -2: "FL_ERR_UNSUPPORTED_SIZE", -3: "FL_ERR_WORKSPACE",
+                 -4: "FL_ERR_NO_DEVICE"}
+        raise FLError(f"{what} failed: {names.get(rc, rc)}")
+
+
+def default_options(solver, **kw):
+    """Reference defaults (NO.f90:73-86, 419-434), overridden by reference-named keywords:
+    Strong, MaxIteration, Precision, MinStepLength, WolfeConst1, WolfeConst2, Increment, Memory,
+    Method ('DY'|'PR'), f_fd (bool: act as if f_fd was passed), clamp."""
+    o = Options()
+    FL.fl_default_options(C.byref(o), solver)
+    ren = {"Strong": "strong", "MaxIteration": "max_iteration", "Precision": "precision",
+           "MinStepLength": "min_step_length", "WolfeConst1": "wolfe_c1", "WolfeConst2": "wolfe_c2",
+           "Increment": "increment", "Memory": "memory", "f_fd": "fused_f_fd", "clamp": "clamp"}
+    for k, v in kw.items():
+        if v is None:
+            continue
+        if k == "Method":
+            if v not in ("DY", "PR"):  # reference: "Program abort: unsupported conjugate gradient method" (NO.f90:345)
+                raise ValueError("unsupported conjugate gradient method " + str(v))
+            o.cg_method = 0 if v == "DY" else 1
+        elif k in ren:
+            setattr(o, ren[k], int(v) if isinstance(v, bool) else v)
+        else:
+            raise TypeError("unknown option " + k)
+    return o
+
+
+def reduction_geometry(n):
+    t, e = C.c_int(), C.c_int()
+    _check(FL.fl_reduction_geometry(n, C.byref(t), C.byref(e)), "fl_reduction_geometry")
+    return t.value, e.value
+
+
+def _stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _prep(x, d, b):
+    import torch
+    if not (x.is_cuda and x.dtype == torch.float64 and x.dim() == 2 and x.is_contiguous()):
+        raise ValueError("x must be a contiguous CUDA float64 tensor [batch, n]")
+    for t in (d, b):
+        if t is not None and not (t.is_cuda and t.dtype == torch.float64 and t.shape == x.shape and t.is_contiguous()):
+            raise ValueError("objective data must be contiguous CUDA float64 tensors shaped like x")
+    B, n = x.shape
+    out = dict(f=torch.empty(B, dtype=torch.float64, device=x.device),
+               gg=torch.empty(B, dtype=torch.float64, device=x.device),
+               iters=torch.empty(B, dtype=torch.int32, device=x.device),
+               status=torch.empty(B, dtype=torch.int32, device=x.device),
+               nf=torch.empty(B, dtype=torch.int32, device=x.device),
+               ng=torch.empty(B, dtype=torch.int32, device=x.device))
+    return B, n, out
+
+
+def workspace(batch, n, memory, device):
+    import torch
+    nbytes = FL.fl_workspace_bytes(LBFGS_, batch, n, memory)
+    return torch.empty(max(nbytes // 8, 1), dtype=torch.float64, device=device)
+
+
+def LBFGS(objective, x, d=None, b=None, workspace_=None, options=None, **kw):
+    """Batched L-BFGS (reference: subroutine LBFGS, NO.f90:398-625). Returns dict of per-problem outputs."""
+    o = options if options is not None else default_options(LBFGS_, **kw)
+    B, n, out = _prep(x, d, b)
+    ws = workspace_ if workspace_ is not None else workspace(B, n, o.memory, x.device)
+    _check(FL.fl_lbfgs_batched(objective, B, n, _ptr(x), _ptr(d), _ptr(b), C.byref(o), _ptr(ws),
+                               ws.numel() * 8, _ptr(out["f"]), _ptr(out["gg"]), _ptr(out["iters"]),
+                               _ptr(out["status"]), _ptr(out["nf"]), _ptr(out["ng"]), _stream()), "fl_lbfgs_batched")
+    out["workspace"] = ws
+    return out
+
+
+def ConjugateGradient(objective, x, d=None, b=None, options=None, **kw):
+    """Batched conjugate gradient, Method='DY'|'PR' (reference: NO.f90:193-394)."""
+    o = options if options is not None else default_options(CG, **kw)
+    B, n, out = _prep(x, d, b)
+    _check(FL.fl_conjugate_gradient_batched(objective, B, n, _ptr(x), _ptr(d), _ptr(b), C.byref(o), _ptr(out["f"]),
+                                            _ptr(out["gg"]), _ptr(out["iters"]), _ptr(out["status"]),
+                                            _ptr(out["nf"]), _ptr(out["ng"]), _stream()),
+           "fl_conjugate_gradient_batched")
+    return out
+
+
+def SteepestDescent(objective, x, d=None, b=None, options=None, **kw):
+    """Batched steepest descent (reference: NO.f90:55-188)."""
+    o = options if options is not None else default_options(SD, **kw)
+    B, n, out = _prep(x, d, b)
+    _check(FL.fl_steepest_descent_batched(objective, B, n, _ptr(x), _ptr(d), _ptr(b), C.byref(o), _ptr(out["f"]),
+                                          _ptr(out["gg"]), _ptr(out["iters"]), _ptr(out["status"]), _ptr(out["nf"]),
+                                          _ptr(out["ng"]), _stream()), "fl_steepest_descent_batched")
+    return out
+
+
+def two_loop(hist, rho, g, p, memory, recent):
+    """Stand-alone batched two-loop recursion (Before(), NO.f90:586-608): p = -H g."""
+    B, n = g.shape
+    _check(FL.fl_lbfgs_two_loop_batched(B, n, memory, recent, _ptr(hist), _ptr(rho), _ptr(g), _ptr(p), _stream()),
+           "fl_lbfgs_two_loop_batched")
+
+
+def synth_uniform(seed, out, lo, hi):
+    B, n = out.shape
+    _check(FL.fl_synth_uniform(seed, B, n, lo, hi, _ptr(out), _stream()), "fl_synth_uniform")
+
+
+def synth_diag_spectrum(seed, out, kappa_lo, kappa_hi):
+    B, n = out.shape
+    _check(FL.fl_synth_diag_spectrum(seed, B, n, kappa_lo, kappa_hi, _ptr(out), _stream()),
+           "fl_synth_diag_spectrum")

@@ -1,0 +1,137 @@
+/*
+ * fl_nlopt.h -- C ABI of libFL.so (MI355X / gfx950): batched line-search optimisers.
+ *
+ * This is the drop-in boundary for the NonlinearOptimization hot path of
+ * YifanShenSZ/Fortran-Library.  Every entry point is extern "C", takes plain
+ * pointers and sizes (no torch / C++ types) and is what a Fortran bind(C)
+ * interface, a C++ header, or Python ctypes binds (INTEGRATION.md shows each).
+ *
+ * Reference interfaces replaced (file:line in /root/reference):
+ *   fl_lbfgs_batched               <- subroutine LBFGS              source/NonlinearOptimization.f90:398-625
+ *   fl_conjugate_gradient_batched  <- subroutine ConjugateGradient   NonlinearOptimization.f90:193-394
+ *                                     (+ ConjugateGradient_basic     NonlinearOptimization.f90:2249-2346,
+ *                                      cpp/NonlinearOptimization.hpp:294-324)
+ *   fl_steepest_descent_batched    <- subroutine SteepestDescent     NonlinearOptimization.f90:55-188
+ *                                     (cpp/NonlinearOptimization.hpp:279-292)
+ *   line search inside all of them <- Wolfe / StrongWolfe (+_fdwithf) NonlinearOptimization.f90:1286-1698
+ *
+ * Differences from the reference, by design: a BATCH of independent problems
+ * per call (problem-major [batch][n] fp64 arrays in device memory), objectives
+ * selected from built-in device functors instead of host callbacks, and
+ * per-problem outputs (objective, iteration / evaluation counts, status) that the
+ * reference never returned.  Option names, defaults, clamps and termination
+ * tests are the reference's (NO.f90:41-51, 73-86, 419-434).
+ *
+ * All pointers named "dev" are device (HBM) pointers.  All calls are
+ * asynchronous on `stream` (a hipStream_t passed as void*, NULL = default
+ * stream); outputs are valid after the stream is synchronised.  Return value:
+ * FL_OK or a negative FL_ERR_* code; nothing is printed and nothing runs on the
+ * CPU as a fallback -- without a usable HIP device every call fails with
+ * FL_ERR_NO_DEVICE.
+ */
+#ifndef FL_NLOPT_H
+#define FL_NLOPT_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FL_OK 0
+#define FL_ERR_INVALID_ARGUMENT (-1) /* NULL pointer, batch/n <= 0, unknown enum */
+#define FL_ERR_UNSUPPORTED_SIZE (-2) /* n or memory beyond what the kernels hold on chip */
+#define FL_ERR_WORKSPACE (-3)        /* workspace missing or too small */
+#define FL_ERR_NO_DEVICE (-4)        /* no HIP device / kernel launch failed */
+
+/* built-in objectives (SURVEY.md section 8d synthetic inputs) */
+#define FL_OBJ_QUARTIC 0    /* f = sum x_i^4                      (test/test.f90:630-663)        */
+#define FL_OBJ_ROSENBROCK 1 /* f = sum_{i<n} 100 (x_{i+1}-x_i^2)^2 + (1-x_i)^2  (chained)       */
+#define FL_OBJ_DIAGQUAD 2   /* f = 1/2 sum d_i x_i^2 - sum b_i x_i ; data d,b [batch][n]         */
+
+/* per-problem exit status */
+#define FL_STATUS_CONVERGED 0      /* g.g < Precision^2                   (NO.f90:612)          */
+#define FL_STATUS_STEP_CONVERGED 1 /* p.p a^2 < MinStepLength^2 "step length has converged" (NO.f90:615) */
+#define FL_STATUS_MAXIT 2          /* MaxIteration exceeded              (NO.f90:580)           */
+
+#define FL_CG_DY 0 /* Dai-Yuan        NO.f90:352-372 */
+#define FL_CG_PR 1 /* Polak-Ribiere+  NO.f90:373-393 */
+
+#define FL_MAX_MEMORY 64 /* largest L-BFGS Memory held by the kernels */
+
+/* The reference's optional arguments (NO.f90:41-51).  fl_default_options fills the
+ * reference defaults; solver-specific default: ConjugateGradient uses
+ * wolfe_c2 = 0.45 (NO.f90:229) -- fl_default_options(opt, FL_SOLVER_CG) does that. */
+typedef struct fl_options {
+    int32_t strong;          /* Strong         : 1 = strong Wolfe (default), 0 = Wolfe            */
+    int32_t max_iteration;   /* MaxIteration   : default 1000                                     */
+    double precision;        /* Precision      : default 1e-15 (squared internally, NO.f90:427)   */
+    double min_step_length;  /* MinStepLength  : default 1e-15 (squared internally)               */
+    double wolfe_c1;         /* WolfeConst1    : default 1e-4                                     */
+    double wolfe_c2;         /* WolfeConst2    : default 0.9 (CG 0.45)                            */
+    double increment;        /* Increment      : default 1.05 (line-search growth factor)         */
+    int32_t memory;          /* L-BFGS Memory  : default 10, clamped to >= 1 (NO.f90:419)         */
+    int32_t cg_method;       /* FL_CG_DY (default) | FL_CG_PR                                     */
+    int32_t fused_f_fd;      /* 1 = behave as if the caller passed f_fd (main loops use the        */
+                             /*     *_fdwithf line searchers, NO.f90:512-527); default 0          */
+    int32_t clamp;           /* 1 = apply the fail-safe clamps on c1,c2 (NO.f90:83-86; default),   */
+                             /* 0 = take them verbatim (ConjugateGradient_basic, NO.f90:2249)     */
+} fl_options;
+
+#define FL_SOLVER_SD 0
+#define FL_SOLVER_CG 1
+#define FL_SOLVER_LBFGS 2
+
+int fl_version(void);
+void fl_default_options(fl_options *opt, int solver);
+
+/* Reduction geometry the kernels use for dimension n: `threads` per problem (one
+ * workgroup), `ept` elements per thread.  Sums are taken per thread over its
+ * elements, then a 64-lane xor butterfly, then waves left to right -- the order
+ * tests replay on the CPU to compare bit for bit.  FL_ERR_UNSUPPORTED_SIZE if n
+ * is too large for the on-chip path. */
+int fl_reduction_geometry(int n, int *threads, int *ept);
+
+/* Bytes of device workspace fl_lbfgs_batched needs (the (s,y) history ring,
+ * [batch][2*memory][padded n] fp64).  0 for SD / CG. */
+size_t fl_workspace_bytes(int solver, int batch, int n, int memory);
+
+/* Batched solvers.  x_dev [batch][n] in/out (initial guess -> minimiser);
+ * d_dev/b_dev [batch][n] objective data (FL_OBJ_DIAGQUAD only, else NULL);
+ * outputs (each may be NULL): f_dev[batch] objective at exit, gg_dev[batch]
+ * squared gradient norm at exit, iters_dev[batch] line searches performed,
+ * status_dev[batch] FL_STATUS_*, nf_dev/ng_dev[batch] f / gradient evaluations
+ * as the reference would have issued them. */
+int fl_lbfgs_batched(int objective, int batch, int n, double *x_dev, const double *d_dev, const double *b_dev,
+                     const fl_options *opt, void *workspace_dev, size_t workspace_bytes, double *f_dev,
+                     double *gg_dev, int32_t *iters_dev, int32_t *status_dev, int32_t *nf_dev, int32_t *ng_dev,
+                     void *stream);
+int fl_conjugate_gradient_batched(int objective, int batch, int n, double *x_dev, const double *d_dev,
+                                  const double *b_dev, const fl_options *opt, double *f_dev, double *gg_dev,
+                                  int32_t *iters_dev, int32_t *status_dev, int32_t *nf_dev, int32_t *ng_dev,
+                                  void *stream);
+int fl_steepest_descent_batched(int objective, int batch, int n, double *x_dev, const double *d_dev,
+                                const double *b_dev, const fl_options *opt, double *f_dev, double *gg_dev,
+                                int32_t *iters_dev, int32_t *status_dev, int32_t *nf_dev, int32_t *ng_dev,
+                                void *stream);
+
+/* The L-BFGS two-loop recursion alone (Before(), NO.f90:586-608) for a batch:
+ * p = -H_k g from a full ring of `memory` pairs.  hist_dev is the solver's
+ * history layout [batch][2*memory][npad] (npad = threads*ept; pair i: s at
+ * row 2i, y at row 2i+1), rho_dev [batch][memory], recent = newest slot.
+ * g_dev, p_dev [batch][n].  Used by bench.py to measure the recursion against
+ * the HBM roofline in isolation. */
+int fl_lbfgs_two_loop_batched(int batch, int n, int memory, int recent, const double *hist_dev,
+                              const double *rho_dev, const double *g_dev, double *p_dev, void *stream);
+
+/* Synthetic inputs, generated on the device with Philox-4x32-10 (key = seed,
+ * counter = (element pair, problem id)); tests replay the same generator with numpy.
+ * out[batch][n] uniform in (lo, hi). */
+int fl_synth_uniform(uint64_t seed, int batch, int n, double lo, double hi, double *out_dev, void *stream);
+/* d[k][i] = 1 + (kappa_k - 1) i/(n-1), kappa_k log-uniform in [kappa_lo, kappa_hi] (one Philox draw per problem) */
+int fl_synth_diag_spectrum(uint64_t seed, int batch, int n, double kappa_lo, double kappa_hi, double *d_dev,
+                           void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,223 @@
+"""GPU parity: the HIP solvers (through libFL.so's C ABI) against the CPU oracle.
+
+Two bars:
+  * BIT-EXACT against the oracle run in FLO_SUM_TREE mode (same algorithm, sums taken in
+    the kernels' reduction order): minimiser, objective, g.g, iteration / evaluation counts
+    and exit status must be identical -- every branch of the line-search machine agrees.
+  * the north-star tolerance against the oracle in FLO_SUM_SEQ mode (the reference's own
+    left-to-right summation, pinned in test_oracle_pins.py): final objective within 1e-10
+    relative (absolute floor 1e-20 when |f*| < 1e-10), minimiser within 1e-8 * max(1, |x*|),
+    on inputs where the reference converges by its gradient test.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _nlo():
+    import FortranLibrary.NonlinearOptimization as NLO
+    return NLO
+
+
+def _gpu_solve(solver, kind, x0, d=None, b=None, **kw):
+    NLO = _nlo()
+    dev = torch.device("cuda:0")
+    x = torch.tensor(np.atleast_2d(x0), dtype=torch.float64, device=dev).contiguous()
+    dd = torch.tensor(np.broadcast_to(d, x.shape).copy(), dtype=torch.float64, device=dev) if d is not None else None
+    bb = torch.tensor(np.broadcast_to(b, x.shape).copy(), dtype=torch.float64, device=dev) if b is not None else None
+    fn = {O.SD: NLO.SteepestDescent, O.CG: NLO.ConjugateGradient, O.LBFGS: NLO.LBFGS}[solver]
+    out = fn(kind, x, dd, bb, **kw)
+    torch.cuda.synchronize()
+    res = {k: v.cpu().numpy() for k, v in out.items() if k != "workspace"}
+    res["x"] = x.cpu().numpy()
+    return res
+
+
+def _oracle_opts(solver, kw):
+    o = O.defaults(c2=0.45 if solver == O.CG else 0.9)
+    ren = {"Strong": "strong", "MaxIteration": "maxit", "Precision": "precision", "MinStepLength": "minstep",
+           "WolfeConst1": "c1", "WolfeConst2": "c2", "Increment": "increment", "Memory": "memory"}
+    for k, v in kw.items():
+        if k == "Method":
+            o.method = 0 if v == "DY" else 1
+        elif k in ren:
+            setattr(o, ren[k], int(v) if isinstance(v, bool) else v)
+    return o
+
+
+def _both(solver, kind, x0, d=None, b=None, mode=O.TREE, **kw):
+    NLO = _nlo()
+    n = np.atleast_2d(x0).shape[1]
+    T, E = NLO.reduction_geometry(n)
+    g = _gpu_solve(solver, kind, x0, d, b, **kw)
+    o = O.solve_batch(solver, kind, x0, d=d, b=b, opts=_oracle_opts(solver, kw), use_ffd=bool(kw.get("f_fd", False)),
+                      sum_mode=mode, threads=T, ept=E)
+    return g, o
+
+
+def _assert_bitexact(g, o):
+    assert np.array_equal(g["iters"], o["iters"]), (g["iters"], o["iters"])
+    assert np.array_equal(g["status"], o["status"])
+    assert np.array_equal(g["nf"], o["nf"]) and np.array_equal(g["ng"], o["ng"]), (g["nf"], o["nf"], g["ng"], o["ng"])
+    assert np.array_equal(g["x"].view(np.uint64), o["x"].view(np.uint64))
+    assert np.array_equal(g["f"].view(np.uint64), o["f"].view(np.uint64))
+    assert np.array_equal(g["gg"].view(np.uint64), o["gg"].view(np.uint64))
+
+
+SOLVERS = [(O.LBFGS, {}), (O.LBFGS, {"Memory": 3}), (O.LBFGS, {"Memory": 1}), (O.LBFGS, {"f_fd": True}),
+           (O.LBFGS, {"Strong": False}), (O.CG, {}), (O.CG, {"Method": "PR"}), (O.CG, {"Strong": False}),
+           (O.CG, {"f_fd": True}), (O.SD, {"MaxIteration": 200}), (O.SD, {"Strong": False, "MaxIteration": 200})]
+
+
+@pytest.mark.parametrize("solver,kw", SOLVERS)
+def test_quartic_dim10_like_reference_test(solver, kw):
+    """test/test.f90:338-388: quartic sum x^4, dim 10; the reference starts from random_number(x)."""
+    rng = np.random.default_rng(7)
+    x0 = np.vstack([0.1 * np.arange(1, 11), rng.random((7, 10))])
+    g, o = _both(solver, O.QUARTIC, x0, **kw)
+    _assert_bitexact(g, o)
+    if solver != O.SD:
+        assert np.all(np.linalg.norm(g["x"], axis=1) < 1e-3)  # "Correct routines should print close to 0"
+
+
+@pytest.mark.parametrize("solver,kw", SOLVERS[:9])
+def test_rosenbrock_n10_standard_start(solver, kw):
+    x0 = np.full((1, 10), -1.2)
+    x0[:, 1::2] = 1.0
+    g, o = _both(solver, O.ROSENBROCK, x0, **kw)
+    _assert_bitexact(g, o)
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 63, 129, 255, 256, 257, 513, 1000, 1024, 2048, 4096])
+def test_rosenbrock_lbfgs_sizes_and_ragged_n(n):
+    """every geometry of the kernel, odd n (unaligned rows), n not filling the workgroup"""
+    rng = np.random.default_rng(n)
+    x0 = 1.0 + 0.1 * rng.uniform(-1, 1, (3, n))
+    g, o = _both(O.LBFGS, O.ROSENBROCK, x0, MaxIteration=60, Precision=1e-9)
+    _assert_bitexact(g, o)
+
+
+@pytest.mark.parametrize("solver,kw", [(O.LBFGS, {}), (O.LBFGS, {"f_fd": True}), (O.CG, {}), (O.CG, {"Method": "PR"})])
+def test_config2_rosenbrock_n256_bitexact(solver, kw):
+    """BASELINE.json config 2 shape (subset of the batch): Rosenbrock n=256, x0 = 1 + 0.1 u"""
+    rng = np.random.default_rng(256)
+    x0 = 1.0 + 0.1 * rng.uniform(-1, 1, (16, 256))
+    g, o = _both(solver, O.ROSENBROCK, x0, Precision=1e-10, MaxIteration=3000, **kw)
+    _assert_bitexact(g, o)
+    if solver == O.LBFGS:
+        assert np.all(g["status"] == O.CONVERGED)
+        assert np.all(np.abs(g["x"] - 1.0) < 1e-8)
+
+
+def _quads(B, n, klo, khi, seed):
+    rng = np.random.default_rng(seed)
+    kappa = np.exp(rng.uniform(np.log(klo), np.log(khi), B))
+    i = np.arange(n) / max(n - 1, 1)
+    d = 1.0 + (kappa[:, None] - 1.0) * i[None, :]
+    b = rng.uniform(-1, 1, (B, n))
+    return d, b
+
+
+@pytest.mark.parametrize("solver,kw", [(O.LBFGS, {}), (O.LBFGS, {"f_fd": True}), (O.CG, {}), (O.CG, {"Method": "PR"}),
+                                       (O.LBFGS, {"Strong": False})])
+def test_config3_diag_quadratics_n1024_bitexact(solver, kw):
+    d, b = _quads(8, 1024, 10.0, 1000.0, 3)
+    g, o = _both(solver, O.DIAGQUAD, np.zeros((8, 1024)), d, b, **kw)
+    _assert_bitexact(g, o)
+
+
+@pytest.mark.parametrize("solver,kw", [(O.LBFGS, {"Precision": 1e-9}), (O.CG, {"Precision": 1e-9}),
+                                       (O.CG, {"Precision": 1e-9, "Method": "PR"})])
+def test_north_star_tolerance_vs_reference_summation(solver, kw):
+    """final f within 1e-10 relative, minimiser within 1e-8, against the reference's summation order"""
+    d, b = _quads(8, 1024, 10.0, 100.0, 5)
+    g, o = _both(solver, O.DIAGQUAD, np.zeros((8, 1024)), d, b, mode=O.SEQ, **kw)
+    assert np.all(g["status"] == O.CONVERGED) and np.all(o["status"] == O.CONVERGED)
+    assert np.all(np.abs(g["f"] - o["f"]) <= 1e-10 * np.abs(o["f"]))
+    xs = b / d
+    assert np.all(np.linalg.norm(g["x"] - o["x"], axis=1) <= 1e-8 * np.maximum(1.0, np.linalg.norm(o["x"], axis=1)))
+    assert np.all(np.linalg.norm(g["x"] - xs, axis=1) <= 1e-7 * np.linalg.norm(xs, axis=1))
+
+
+def test_rosenbrock_tolerance_vs_reference_summation():
+    rng = np.random.default_rng(11)
+    x0 = 1.0 + 0.1 * rng.uniform(-1, 1, (8, 256))
+    g, o = _both(O.LBFGS, O.ROSENBROCK, x0, mode=O.SEQ, Precision=1e-10, MaxIteration=3000)
+    assert np.all(g["status"] == O.CONVERGED) and np.all(o["status"] == O.CONVERGED)
+    assert np.all(np.abs(g["f"] - o["f"]) <= 1e-20)  # f* = 0: absolute floor
+    assert np.all(np.linalg.norm(g["x"] - o["x"], axis=1) <= 1e-8 * np.linalg.norm(o["x"], axis=1))
+
+
+def test_already_converged_start_and_status_codes():
+    g, o = _both(O.LBFGS, O.ROSENBROCK, np.ones((2, 64)))
+    _assert_bitexact(g, o)
+    assert np.all(g["iters"] == 0) and np.all(g["status"] == O.CONVERGED)
+    x0 = np.full((1, 256), -1.2)
+    x0[:, 1::2] = 1.0
+    g, o = _both(O.LBFGS, O.ROSENBROCK, x0, MaxIteration=50)
+    _assert_bitexact(g, o)
+    assert g["status"][0] == O.MAXIT and g["iters"][0] == 50 + 10
+
+
+def test_argument_errors_and_no_cpu_fallback():
+    NLO = _nlo()
+    x = torch.zeros(2, 5000, dtype=torch.float64, device="cuda:0")
+    with pytest.raises(NLO.FLError):  # n beyond the on-chip path
+        NLO.LBFGS(O.ROSENBROCK, x)
+    x = torch.zeros(2, 16, dtype=torch.float64, device="cuda:0")
+    with pytest.raises(NLO.FLError):  # quadratic data missing
+        NLO.LBFGS(O.DIAGQUAD, x)
+    with pytest.raises(ValueError):
+        NLO.ConjugateGradient(O.QUARTIC, x, Method="XX")
+    with pytest.raises(ValueError):
+        NLO.LBFGS(O.QUARTIC, torch.zeros(2, 16, dtype=torch.float64))  # host tensor: refused, never solved on CPU
+
+
+def test_philox_generators_match_numpy_replay():
+    NLO = _nlo()
+    from philox_ref import philox_uniform, philox_spectrum
+    out = torch.empty(5, 33, dtype=torch.float64, device="cuda:0")
+    NLO.synth_uniform(20261003, out, -1.0, 1.0)
+    assert np.array_equal(out.cpu().numpy(), philox_uniform(20261003, 5, 33, -1.0, 1.0))
+    NLO.synth_diag_spectrum(20261003, out, 10.0, 1000.0)
+    ref = philox_spectrum(20261003, 5, 33, 10.0, 1000.0)
+    assert np.allclose(out.cpu().numpy(), ref, rtol=1e-14, atol=0)
+
+
+def test_two_loop_kernel_matches_solver_direction():
+    """stand-alone two-loop kernel == numpy two-loop on the same history (tolerance: different summation)"""
+    NLO = _nlo()
+    rng = np.random.default_rng(0)
+    B, n, m = 4, 1024, 10
+    T, E = NLO.reduction_geometry(n)
+    npad = T * E
+    S = rng.standard_normal((B, m, n)) * 0.1
+    Y = S * rng.uniform(1, 10, (B, 1, n)) + 0.01 * rng.standard_normal((B, m, n))
+    g = rng.standard_normal((B, n))
+    hist = np.zeros((B, 2 * m, npad))
+    hist[:, 0::2, :n] = S
+    hist[:, 1::2, :n] = Y
+    rho = 1.0 / np.einsum("bmn,bmn->bm", Y, S)
+    recent = 6
+    dev = "cuda:0"
+    p = torch.empty(B, n, dtype=torch.float64, device=dev)
+    NLO.two_loop(torch.tensor(hist, device=dev), torch.tensor(rho, device=dev), torch.tensor(g, device=dev), p, m,
+                 recent)
+    torch.cuda.synchronize()
+    for k in range(B):
+        q = g[k].copy()
+        order = [(recent - j) % m for j in range(m)]
+        al = {}
+        for i in order:
+            al[i] = rho[k, i] * S[k, i].dot(q)
+            q -= al[i] * Y[k, i]
+        q = q / rho[k, recent] / Y[k, recent].dot(Y[k, recent])
+        for i in reversed(order):
+            be = rho[k, i] * Y[k, i].dot(q)
+            q += (al[i] - be) * S[k, i]
+        assert np.allclose(p[k].cpu().numpy(), -q, rtol=1e-9, atol=1e-12)
