@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/fl_nlopt.h"
+#include "fl_reduce.hpp"
 
 namespace fl {
 
@@ -67,13 +68,6 @@ __global__ void synth_spectrum_kernel(uint64_t seed, int batch, int n, double ll
 // Stand-alone two-loop recursion.  Same register layout, reduction order and
 // load pipeline as the solver kernel (fl_solver_kernels.hip): one workgroup per
 // problem, p in registers, 4*m history rows streamed from HBM.
-__device__ __forceinline__ double wave_allreduce2(double v)
-{
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) v = v + __shfl_xor(v, off, 64);
-    return v;
-}
-
 template <int NW, int EPT>
 __global__ __launch_bounds__(NW * 64) void two_loop_kernel(int n, int mem, int recent, const double *hist_all,
                                                            const double *rho_all, const double *g_all, double *p_all)
@@ -86,7 +80,7 @@ __global__ __launch_bounds__(NW * 64) void two_loop_kernel(int n, int mem, int r
     if (tid < mem) rho_s[tid] = rho_all[(size_t)prob * mem + tid];
     int parity = 0;
     auto reduce = [&](double v) {
-        v = wave_allreduce2(v);
+        v = wave_allreduce(v);
         if constexpr (NW > 1) {
             double *s = slots + parity * NW;
             if ((tid & 63) == 0) s[tid >> 6] = v;

@@ -52,6 +52,32 @@ struct LineSearch {
     int st, zret;
     double a_eval; // where the pending request is to be evaluated
 
+    // Every value of the machine is uniform across the workgroup.  On the GPU, pin the state to
+    // scalar registers after each step (v_readfirstlane) so that it does not occupy one vector
+    // register pair per value in every lane; a no-op on the host.
+    FL_HD static double uni(double v)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+        const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+        return __hiloint2double(hi, lo);
+#else
+        return v;
+#endif
+    }
+    FL_HD void uniformize()
+    {
+        c1 = uni(c1); c2abs = uni(c2abs); incr = uni(incr); fx0 = uni(fx0); phid0 = uni(phid0);
+        a = uni(a); aold = uni(aold); fx = uni(fx); fold = uni(fold); phidnew = uni(phidnew); phidold = uni(phidold);
+        low = uni(low); up = uni(up); flow = uni(flow); fup = uni(fup); phidlow = uni(phidlow); phidup = uni(phidup);
+        plma = uni(plma); a_eval = uni(a_eval);
+#if defined(__HIP_DEVICE_COMPILE__)
+        st = __builtin_amdgcn_readfirstlane(st);
+        zret = __builtin_amdgcn_readfirstlane(zret);
+        fused = __builtin_amdgcn_readfirstlane(fused);
+#endif
+    }
+
     FL_HD static double dmax(double u, double v) { return u > v ? u : v; }
     FL_HD static double dmin(double u, double v) { return u < v ? u : v; }
 
@@ -80,6 +106,8 @@ struct LineSearch {
         c2abs = c2_ * fabs(phid0_in);
         a = a0;
         zret = 0;
+        aold = fold = phidnew = phidold = 0.0;
+        low = up = flow = fup = phidlow = phidup = plma = 0.0;
         if (strong) {
             st = SW_FIRST;
             return req(fused ? (FL_REQ_F | FL_REQ_G) : FL_REQ_F, a, 0);

@@ -17,8 +17,8 @@
 //     only HBM-bound phase, and its loads for step j+1 are in flight while
 //     step j reduces.
 //   * dot products: per-thread partial over the EPT elements, 64-lane xor
-//     butterfly (__shfl_xor 1,2,4,...,32), then the NW wave partials summed left
-//     to right through LDS.  The order is fixed, so results are reproducible
+//     butterfly (DPP + v_permlane swaps, fl_reduce.hpp), then the NW wave partials
+//     summed left to right through LDS.  The order is fixed, so results are reproducible
 //     bit for bit (tests replay it on the CPU).
 //   * all scalars of the line-search machine are workgroup-uniform: every branch
 //     is taken by all threads, barriers are safe inside the state machine.
@@ -29,6 +29,13 @@
 #include <stdint.h>
 #include "../../include/fl_nlopt.h"
 #include "fl_linesearch.hpp"
+#include "fl_reduce.hpp"
+
+#ifdef FL_MIN_WPE
+#define FL_OCC_ATTR __attribute__((amdgpu_waves_per_eu(FL_MIN_WPE)))
+#else
+#define FL_OCC_ATTR
+#endif
 
 namespace fl {
 
@@ -44,42 +51,6 @@ struct SolveArgs {
 
 template <int EPT> struct Vec {
     double v[EPT];
-};
-
-__device__ __forceinline__ double wave_allreduce(double v)
-{
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) v = v + __shfl_xor(v, off, 64);
-    return v;
-}
-
-// workgroup all-reduce of NV values; every thread gets bitwise identical totals
-template <int NW> struct Reducer {
-    double *slots; // LDS [2][NVMAX][NW]
-    int parity;
-    static constexpr int NVMAX = 4;
-    template <int NV> __device__ __forceinline__ void run(double (&v)[NV])
-    {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) v[i] = wave_allreduce(v[i]);
-        if constexpr (NW > 1) {
-            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-            double *s = slots + parity * (NVMAX * NW);
-            if (lane == 0) {
-#pragma unroll
-                for (int i = 0; i < NV; ++i) s[i * NW + wave] = v[i];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                double t = s[i * NW];
-#pragma unroll
-                for (int w = 1; w < NW; ++w) t = t + s[i * NW + w];
-                v[i] = t;
-            }
-            parity ^= 1;
-        }
-    }
 };
 
 template <int NW, int EPT> struct Geo {
@@ -256,7 +227,7 @@ template <int NW, int EPT> struct Objective<FL_OBJ_ROSENBROCK, NW, EPT> {
 
 // ------------------------------------------------------------ the solver
 template <int NW, int EPT, int OBJ, int METHOD>
-__global__ __launch_bounds__(NW * 64) void fl_solve_kernel(SolveArgs A)
+__global__ __launch_bounds__(NW * 64) FL_OCC_ATTR void fl_solve_kernel(SolveArgs A)
 {
     using G = Geo<NW, EPT>;
     using Obj = Objective<OBJ, NW, EPT>;
@@ -264,12 +235,15 @@ __global__ __launch_bounds__(NW * 64) void fl_solve_kernel(SolveArgs A)
     __shared__ double red_slots[2 * 4 * NW];
     __shared__ double rho_s[FL_MAX_MEMORY], alpha_s[FL_MAX_MEMORY];
     __shared__ double xs[Obj::LDS_DOUBLES > 0 ? Obj::LDS_DOUBLES : 1];
+    // gold (the gradient before the line search) is parked in LDS for the duration of the search:
+    // every thread writes and later reads back only its own 16-byte chunks (no barrier needed)
+    __shared__ __attribute__((aligned(16))) double g0s[METHOD == FL_SOLVER_SD ? 2 : NPAD];
 
     const int prob = blockIdx.x;
     const int n = A.n;
     Reducer<NW> R4{red_slots, 0};
 
-    double x[EPT], g[EPT], p[EPT], x0[EPT], g0[EPT];
+    double x[EPT], g[EPT], p[EPT], x0[EPT];
     Obj obj;
     obj.init(A, prob, xs);
     load_user<NW, EPT>(A.x + (size_t)prob * n, n, x);
@@ -283,9 +257,9 @@ __global__ __launch_bounds__(NW * 64) void fl_solve_kernel(SolveArgs A)
         r[2] = dot_part<EPT>(g, p);
         r[3] = dot_part<EPT>(g, g);
         R4.run(r);
-        f = Obj::combine(r[0], r[1]);
-        gp = r[2];
-        gg = r[3];
+        f = LineSearch::uni(Obj::combine(r[0], r[1]));
+        gp = LineSearch::uni(r[2]);
+        gg = LineSearch::uni(r[3]);
     };
 
     int nf = 1, ng = 1, iters = 0, status = FL_STATUS_CONVERGED;
@@ -312,7 +286,11 @@ __global__ __launch_bounds__(NW * 64) void fl_solve_kernel(SolveArgs A)
 #pragma unroll
         for (int k = 0; k < EPT; ++k) { // xold=x; fdold=fdnew (x0 doubles as the line search's x0)
             x0[k] = x[k];
-            g0[k] = g[k];
+        }
+        if constexpr (METHOD != FL_SOLVER_SD) {
+#pragma unroll
+            for (int c = 0; c < G::NCH; ++c)
+                *reinterpret_cast<double2 *>(g0s + G::e0(c)) = make_double2(g[2 * c], g[2 * c + 1]);
         }
         const double phidold = phid;
         // which searcher: the *_fdwithf variants only in main loops with f_fd present
@@ -323,6 +301,7 @@ __global__ __launch_bounds__(NW * 64) void fl_solve_kernel(SolveArgs A)
 
         LineSearch ls;
         int rq = ls.begin(strong, fused, A.c1, A.c2, A.incr, a, fnew, phid);
+        ls.uniformize();
         double fv = fnew, pv = phid;
         while (rq) {
             if (!(rq & FL_REQ_SAME)) {
@@ -333,11 +312,21 @@ __global__ __launch_bounds__(NW * 64) void fl_solve_kernel(SolveArgs A)
             }
             nf += (rq & FL_REQ_F) ? 1 : 0;
             ng += (rq & FL_REQ_G) ? 1 : 0;
-            rq = ls.step(fv, pv);
+            rq = __builtin_amdgcn_readfirstlane(ls.step(fv, pv));
+            ls.uniformize();
         }
         a = ls.a;
         fnew = ls.fx;
         ++iters;
+        double g0[EPT];
+        if constexpr (METHOD != FL_SOLVER_SD) {
+#pragma unroll
+            for (int c = 0; c < G::NCH; ++c) {
+                const double2 t = *reinterpret_cast<const double2 *>(g0s + G::e0(c));
+                g0[2 * c] = t.x;
+                g0[2 * c + 1] = t.y;
+            }
+        }
 
         // convergence tests on the new gradient (After / DY / PR, NO.f90:171-183, 353-364, 610-621)
         if (gg < A.tol) {
@@ -467,6 +456,9 @@ __global__ __launch_bounds__(NW * 64) void fl_solve_kernel(SolveArgs A)
             pp = r[1];
             a = 1.0;
         }
+        phid = LineSearch::uni(phid);
+        pp = LineSearch::uni(pp);
+        a = LineSearch::uni(a);
     }
 
     store_user<NW, EPT>(A.x + (size_t)prob * n, n, x);
