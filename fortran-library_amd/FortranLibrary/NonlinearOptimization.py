@@ -14,7 +14,7 @@ from .basic import FL
 
 QUARTIC, ROSENBROCK, DIAGQUAD = 0, 1, 2
 CONVERGED, STEP_CONVERGED, MAXIT = 0, 1, 2
-SD, CG, LBFGS_ = 0, 1, 2
+SD, CG, LBFGS_, BFGS_ = 0, 1, 2, 3
 OK = 0
 
 
@@ -38,6 +38,10 @@ FL.fl_lbfgs_batched.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.POIN
 _cg_sd = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.POINTER(Options), _dp, _dp, _ip, _ip, _ip, _ip, _vp]
 FL.fl_conjugate_gradient_batched.argtypes = _cg_sd
 FL.fl_steepest_descent_batched.argtypes = _cg_sd
+FL.fl_bfgs_batched.argtypes = FL.fl_lbfgs_batched.argtypes
+FL.fl_augmented_lagrangian_batched.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp,
+                                               C.c_double, C.POINTER(Options), _vp, C.c_size_t, _dp, _dp, _ip, _ip,
+                                               _ip, _ip, _ip, _vp]
 FL.fl_lbfgs_two_loop_batched.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _vp]
 FL.fl_synth_uniform.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_double, _dp, _vp]
 FL.fl_synth_diag_spectrum.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_double, _dp, _vp]
@@ -145,6 +149,56 @@ def SteepestDescent(objective, x, d=None, b=None, options=None, **kw):
     _check(FL.fl_steepest_descent_batched(objective, B, n, _ptr(x), _ptr(d), _ptr(b), C.byref(o), _ptr(out["f"]),
                                           _ptr(out["gg"]), _ptr(out["iters"]), _ptr(out["status"]), _ptr(out["nf"]),
                                           _ptr(out["ng"]), _stream()), "fl_steepest_descent_batched")
+    return out
+
+
+def bfgs_workspace(batch, n, device):
+    import torch
+    nbytes = FL.fl_workspace_bytes(BFGS_, batch, n, 0)
+    return torch.empty(max(nbytes // 8, 1), dtype=torch.float64, device=device)
+
+
+def BFGS(objective, x, d=None, b=None, workspace_=None, options=None, **kw):
+    """Batched dense BFGS, the reference's ExactStep<=0 path (subroutine BFGS, NO.f90:632-1022)."""
+    if kw.pop("ExactStep", 0) > 0:
+        raise NotImplementedError("exact-Hessian refresh (ExactStep > 0) is not on the device path yet")
+    o = options if options is not None else default_options(BFGS_, **kw)
+    B, n, out = _prep(x, d, b)
+    ws = workspace_ if workspace_ is not None else bfgs_workspace(B, n, x.device)
+    _check(FL.fl_bfgs_batched(objective, B, n, _ptr(x), _ptr(d), _ptr(b), C.byref(o), _ptr(ws), ws.numel() * 8,
+                              _ptr(out["f"]), _ptr(out["gg"]), _ptr(out["iters"]), _ptr(out["status"]),
+                              _ptr(out["nf"]), _ptr(out["ng"]), _stream()), "fl_bfgs_batched")
+    out["workspace"] = ws
+    return out
+
+
+def AugmentedLagrangian(objective, x, M, d=None, b=None, UnconstrainedSolver="LBFGS", lambda0=None, miu0=1.0,
+                        workspace_=None, options=None, **kw):
+    """Batched augmented Lagrangian with M block-sphere equality constraints (reference: subroutine
+    AugmentedLagrangian, NO.f90:2005-2241).  UnconstrainedSolver: 'LBFGS' | 'ConjugateGradient'.
+    lambda0: optional [batch, M] tensor, updated in place (returned as out['lambda'])."""
+    import torch
+    solvers = {"LBFGS": LBFGS_, "ConjugateGradient": CG}
+    if UnconstrainedSolver not in solvers:  # reference: "Program abort: unsupported unconstrained solver" (NO.f90:2186)
+        raise ValueError("unsupported unconstrained solver on the device path: " + str(UnconstrainedSolver))
+    solver = solvers[UnconstrainedSolver]
+    o = options if options is not None else default_options(solver, **kw)
+    B, n, out = _prep(x, d, b)
+    lam = lambda0 if lambda0 is not None else torch.zeros(B, M, dtype=torch.float64, device=x.device)
+    ws = workspace_
+    if ws is None:
+        ws = workspace(B, n, o.memory, x.device) if solver == LBFGS_ else torch.empty(1, dtype=torch.float64,
+                                                                                      device=x.device)
+    out["outer"] = torch.empty(B, dtype=torch.int32, device=x.device)
+    out["cnorm2"] = torch.empty(B, dtype=torch.float64, device=x.device)
+    _check(FL.fl_augmented_lagrangian_batched(solver, objective, B, n, M, _ptr(x), _ptr(d), _ptr(b), _ptr(lam),
+                                              miu0, C.byref(o), _ptr(ws), ws.numel() * 8, _ptr(out["f"]),
+                                              _ptr(out["cnorm2"]), _ptr(out["iters"]), _ptr(out["outer"]),
+                                              _ptr(out["status"]), _ptr(out["nf"]), _ptr(out["ng"]), _stream()),
+           "fl_augmented_lagrangian_batched")
+    out["lambda"] = lam
+    out["workspace"] = ws
+    del out["gg"]
     return out
 
 

@@ -1,0 +1,763 @@
+// fl_device.hpp -- device-side building blocks of the batched solvers (gfx950).
+//
+// Reference semantics: /root/reference/source/NonlinearOptimization.f90 ("NO.f90")
+//   SteepestDescent 55-188, ConjugateGradient 193-394 (DY 352-372, PR 373-393),
+//   LBFGS 398-625 (pre-iteration 472-510, Before 586-608, After 609-624),
+//   BFGS 632-1022 (first step 683-716, After_NoHessian 996-1015),
+//   AugmentedLagrangian 2005-2241 (L, Ld, L_Ld 2193-2228),
+//   line searchers 1286-1698 (fl_linesearch.hpp).
+//
+// One workgroup owns one problem.  Its vectors live in registers: thread t of the
+// T = 64*NW threads holds EPT elements, dealt in 16-byte chunks round-robin
+// (element (c*T + t)*2 + j), so every global access is a coalesced dwordx4 stream.
+// The solver is written as a resumable machine: start() / advance() return the next
+// evaluation request (FL_REQ_* bits, fl_linesearch.hpp).  The fused kernels answer
+// the request with a compiled-in objective and loop; the reverse-communication kernel
+// (fl_rci.hip) saves the machine to HBM and lets the caller evaluate.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/fl_nlopt.h"
+#include "fl_linesearch.hpp"
+#include "fl_reduce.hpp"
+
+#define FL_REQ_NOMOVE 8 // evaluate at the current x (do not form x0 + a p)
+#define FL_MAX_CONSTRAINTS 16
+
+namespace fl {
+
+struct SolveArgs {
+    int n, batch, mem, maxit, strong, fused, cg_method;
+    double tol, minstep, c1, c2, incr;
+    double *x;
+    const double *d, *b;
+    double *hist; // L-BFGS ring [batch][2*mem][NPAD]  |  BFGS inverse Hessian [batch][n][NPAD]
+    double *f_out, *gg_out;
+    int *iters, *status, *nf, *ng;
+    // augmented Lagrangian (NO.f90:2005): m block-sphere constraints
+    int aug_m;
+    double miu0, precision; // outer tolerance = Precision (unsquared, NO.f90:2047, 2072)
+    double *lambda;         // [batch][aug_m] in/out
+    int *outer;
+    double *cnorm2;
+};
+
+template <int NW, int EPT> struct Geo {
+    static constexpr int T = NW * 64;
+    static constexpr int NPAD = T * EPT;
+    static constexpr int NCH = EPT / 2;
+    __device__ __forceinline__ static int e0(int c) { return ((c * T + (int)threadIdx.x) << 1); }
+};
+
+__device__ __forceinline__ double uni(double v) { return LineSearch::uni(v); }
+
+// ---- global <-> register vectors.  User arrays are [batch][n] (row stride n);
+// rows are 16-byte aligned iff n is even.
+template <int NW, int EPT> __device__ __forceinline__ void load_user(const double *row, int n, double (&v)[EPT])
+{
+    using G = Geo<NW, EPT>;
+    const bool vec = (n & 1) == 0;
+#pragma unroll
+    for (int c = 0; c < G::NCH; ++c) {
+        const int e = G::e0(c);
+        if (vec && e + 1 < n) {
+            const double2 t = *reinterpret_cast<const double2 *>(row + e);
+            v[2 * c] = t.x;
+            v[2 * c + 1] = t.y;
+        } else {
+            v[2 * c] = (e < n) ? row[e] : 0.0;
+            v[2 * c + 1] = (e + 1 < n) ? row[e + 1] : 0.0;
+        }
+    }
+}
+template <int NW, int EPT> __device__ __forceinline__ void store_user(double *row, int n, const double (&v)[EPT])
+{
+    using G = Geo<NW, EPT>;
+    const bool vec = (n & 1) == 0;
+#pragma unroll
+    for (int c = 0; c < G::NCH; ++c) {
+        const int e = G::e0(c);
+        if (vec && e + 1 < n) {
+            *reinterpret_cast<double2 *>(row + e) = make_double2(v[2 * c], v[2 * c + 1]);
+        } else {
+            if (e < n) row[e] = v[2 * c];
+            if (e + 1 < n) row[e + 1] = v[2 * c + 1];
+        }
+    }
+}
+// padded rows (NPAD doubles, 16-byte aligned): HBM workspaces and LDS parking
+template <int NW, int EPT> __device__ __forceinline__ void load_pad(const double *row, double (&v)[EPT])
+{
+    using G = Geo<NW, EPT>;
+#pragma unroll
+    for (int c = 0; c < G::NCH; ++c) {
+        const double2 t = *reinterpret_cast<const double2 *>(row + G::e0(c));
+        v[2 * c] = t.x;
+        v[2 * c + 1] = t.y;
+    }
+}
+template <int NW, int EPT> __device__ __forceinline__ void store_pad(double *row, const double (&v)[EPT])
+{
+    using G = Geo<NW, EPT>;
+#pragma unroll
+    for (int c = 0; c < G::NCH; ++c)
+        *reinterpret_cast<double2 *>(row + G::e0(c)) = make_double2(v[2 * c], v[2 * c + 1]);
+}
+
+template <int EPT> __device__ __forceinline__ double dot_part(const double (&a)[EPT], const double (&b)[EPT])
+{
+    double acc = a[0] * b[0];
+#pragma unroll
+    for (int k = 1; k < EPT; ++k) acc = acc + a[k] * b[k];
+    return acc;
+}
+
+// ------------------------------------------------------------ objectives
+// eval(): gradient of the thread's EPT elements and up to two partial sums
+// (f = combine(S0, S1)).  Padded elements (e >= n) carry x = 0 and must give g = 0
+// and zero terms.
+template <int OBJ, int NW, int EPT> struct Objective;
+
+template <int NW, int EPT> struct Objective<FL_OBJ_QUARTIC, NW, EPT> { // test/test.f90:630-663
+    static constexpr int LDS_DOUBLES = 0;
+    __device__ __forceinline__ void init(const SolveArgs &, int, double *) {}
+    __device__ __forceinline__ void eval(const double (&x)[EPT], double (&g)[EPT], double &s0, double &s1, int,
+                                         double *)
+    {
+        s1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const double x3 = x[k] * x[k] * x[k]; // x**3 = (x*x)*x
+            const double t = x3 * x[k];           // x**4 = ((x*x)*x)*x
+            g[k] = 4.0 * x3;
+            s0 = (k == 0) ? t : s0 + t;
+        }
+    }
+    __device__ __forceinline__ static double combine(double s0, double) { return s0; }
+};
+
+template <int NW, int EPT> struct Objective<FL_OBJ_DIAGQUAD, NW, EPT> { // f=0.5*sum(d*x*x)-sum(b*x), g=d*x-b
+    static constexpr int LDS_DOUBLES = 0;
+    double d[EPT], b[EPT];
+    __device__ __forceinline__ void init(const SolveArgs &A, int prob, double *)
+    {
+        load_user<NW, EPT>(A.d + (size_t)prob * A.n, A.n, d);
+        load_user<NW, EPT>(A.b + (size_t)prob * A.n, A.n, b);
+    }
+    __device__ __forceinline__ void eval(const double (&x)[EPT], double (&g)[EPT], double &s0, double &s1, int,
+                                         double *)
+    {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const double dx = d[k] * x[k];
+            const double t0 = dx * x[k], t1 = b[k] * x[k];
+            g[k] = dx - b[k];
+            s0 = (k == 0) ? t0 : s0 + t0;
+            s1 = (k == 0) ? t1 : s1 + t1;
+        }
+    }
+    __device__ __forceinline__ static double combine(double s0, double s1) { return 0.5 * s0 - s1; }
+};
+
+template <int NW, int EPT> struct Objective<FL_OBJ_ROSENBROCK, NW, EPT> {
+    // chained Rosenbrock; x is staged through LDS (one halo element each side) so
+    // that every thread can read its chunk's neighbours x[e-1], x[e+2]
+    using G = Geo<NW, EPT>;
+    static constexpr int LDS_DOUBLES = G::NPAD + 2;
+    __device__ __forceinline__ void init(const SolveArgs &, int, double *xs)
+    {
+        if (threadIdx.x == 0) {
+            xs[0] = 0.0;
+            xs[G::NPAD + 1] = 0.0;
+        }
+    }
+    __device__ __forceinline__ void eval(const double (&x)[EPT], double (&g)[EPT], double &s0, double &s1, int n,
+                                         double *xs)
+    {
+        s1 = 0.0;
+        __syncthreads(); // previous trial's neighbour reads are complete
+#pragma unroll
+        for (int c = 0; c < G::NCH; ++c) {
+            const int e = G::e0(c);
+            xs[1 + e] = x[2 * c];
+            xs[2 + e] = x[2 * c + 1];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < G::NCH; ++c) {
+            const int e = G::e0(c);
+            const double xa = x[2 * c], xb = x[2 * c + 1];
+            const double xl = xs[e], xr = xs[e + 3]; // x[e-1], x[e+2]
+            const double ul = xa - xl * xl;          // u_{e-1}
+            const double ua = xb - xa * xa;          // u_e
+            const double ub = xr - xb * xb;          // u_{e+1}
+            const double va = 1.0 - xa, vb = 1.0 - xb;
+            const double A_a = (e >= 1) ? 200.0 * ul : 0.0;
+            const double A_b = 200.0 * ua;
+            double ta = 0.0, tb = 0.0, ga = 0.0, gb = 0.0;
+            if (e <= n - 2) {
+                ta = 100.0 * (ua * ua) + va * va;
+                ga = A_a - 400.0 * xa * ua - 2.0 * va;
+            } else if (e == n - 1) {
+                ga = A_a;
+            }
+            if (e + 1 <= n - 2) {
+                tb = 100.0 * (ub * ub) + vb * vb;
+                gb = A_b - 400.0 * xb * ub - 2.0 * vb;
+            } else if (e + 1 == n - 1) {
+                gb = A_b;
+            }
+            g[2 * c] = ga;
+            g[2 * c + 1] = gb;
+            s0 = (c == 0) ? ta : s0 + ta;
+            s0 = s0 + tb;
+        }
+    }
+    __device__ __forceinline__ static double combine(double s0, double) { return s0; }
+};
+
+// ------------------------------------------------------------ the solver machine
+// METHOD: FL_SOLVER_SD | FL_SOLVER_CG | FL_SOLVER_LBFGS | FL_SOLVER_BFGS.
+// AUG = 1 wraps the objective in the augmented Lagrangian with aug_m block-sphere
+// constraints c_j = sum_{i in block j} x_i^2 - 1 (blocks of n/aug_m) and runs the
+// reference's outer loop (NO.f90:2150-2185) around the inner solver.
+template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
+    using G = Geo<NW, EPT>;
+    using Obj = Objective<OBJ, NW, EPT>;
+    static constexpr int NPAD = G::NPAD;
+    static constexpr int BF_UNROLL = 4;
+    static constexpr bool NEEDS_G0 = (METHOD != FL_SOLVER_SD);
+    // LDS carve (doubles)
+    static constexpr int L_RED = 0;                              // [2][NVMAX][NW]
+    static constexpr int L_RHO = L_RED + 2 * Reducer<NW>::NVMAX * NW;
+    static constexpr int L_ALPHA = L_RHO + FL_MAX_MEMORY;
+    static constexpr int L_LAM = L_ALPHA + FL_MAX_MEMORY;        // lambda[FL_MAX_CONSTRAINTS]
+    static constexpr int L_CX = L_LAM + FL_MAX_CONSTRAINTS;      // c(x)[FL_MAX_CONSTRAINTS]
+    static constexpr int L_XS = (L_CX + FL_MAX_CONSTRAINTS + 1) & ~1;
+    static constexpr int L_G0 = (L_XS + (Obj::LDS_DOUBLES > 0 ? Obj::LDS_DOUBLES : 0) + 1) & ~1;
+    // BFGS: s, q, g broadcast arrays; the first one doubles as the g_old parking slot (the
+    // broadcast arrays are only live inside direction_bfgs, g_old only outside it)
+    static constexpr int L_BF = L_G0 + ((NEEDS_G0 && METHOD != FL_SOLVER_BFGS) ? NPAD : 0);
+    static constexpr int LDS_TOTAL = L_BF + (METHOD == FL_SOLVER_BFGS ? 3 * NPAD : 0);
+
+    const SolveArgs &A;
+    double *lds;
+    int prob, n;
+    Reducer<NW> R;
+    Obj obj;
+    double x[EPT], g[EPT], p[EPT], x0[EPT];
+    // uniform scalars
+    double fnew, gg, pp, phid, phidold, a;
+    int iters, nf, ng, status, phase, pending;
+    int recent, cnt;    // L-BFGS ring
+    double yy_recent, rho_recent;
+    LineSearch ls;
+    // augmented Lagrangian
+    double miu, cc;
+    int outer_it, inner_iters_total;
+
+    enum { PH_INIT = 0, PH_LS = 1, PH_DONE = 2 };
+
+    __device__ __forceinline__ Solver(const SolveArgs &A_, double *lds_)
+        : A(A_), lds(lds_), prob(blockIdx.x), n(A_.n), R{lds_ + L_RED, 0}
+    {
+    }
+
+    __device__ __forceinline__ double *hist_base() const
+    {
+        if constexpr (METHOD == FL_SOLVER_LBFGS) return A.hist + (size_t)prob * (size_t)(2 * A.mem) * NPAD;
+        if constexpr (METHOD == FL_SOLVER_BFGS) return A.hist + (size_t)prob * (size_t)n * NPAD;
+        return nullptr;
+    }
+
+    // ---------------------------------------------------------------- setup
+    __device__ __forceinline__ void init()
+    {
+        obj.init(A, prob, lds + L_XS);
+        load_user<NW, EPT>(A.x + (size_t)prob * n, n, x);
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) p[k] = 0.0;
+        iters = nf = ng = 0;
+        status = FL_STATUS_CONVERGED;
+        recent = -1;
+        cnt = 0;
+        yy_recent = rho_recent = 0.0;
+        fnew = gg = pp = phid = phidold = a = 0.0;
+        outer_it = 0;
+        inner_iters_total = 0;
+        cc = 0.0;
+        miu = 0.0;
+        if constexpr (AUG) {
+            miu = A.miu0 > 1.0 ? A.miu0 : 1.0; // miu=max(1d0,miu0)
+            if ((int)threadIdx.x < A.aug_m) lds[L_LAM + threadIdx.x] = A.lambda[(size_t)prob * A.aug_m + threadIdx.x];
+            __syncthreads();
+        }
+    }
+    __device__ __forceinline__ int start()
+    {
+        phase = PH_INIT;
+        pending = FL_REQ_F | FL_REQ_G | FL_REQ_NOMOVE;
+        return pending;
+    }
+
+    // ---------------------------------------------------------------- evaluation (built-in objectives)
+    __device__ __forceinline__ void move(double at)
+    {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) x[k] = x0[k] + at * p[k];
+    }
+    // f, g.p, g.g at x; with AUG the objective is the augmented Lagrangian
+    __device__ __forceinline__ void evaluate(double &f, double &gp, double &ggo)
+    {
+        double r[4];
+        obj.eval(x, g, r[0], r[1], n, lds + L_XS);
+        if constexpr (AUG) {
+            // c_j: masked full-width sums of x^2 (one reduction of aug_m values with the objective's)
+            const int m = A.aug_m, w = n / m;
+            double cj[FL_MAX_CONSTRAINTS];
+#pragma unroll
+            for (int j = 0; j < FL_MAX_CONSTRAINTS; ++j) {
+                cj[j] = 0.0;
+                if (j < m) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int k = 0; k < EPT; ++k) {
+                        const int e = G::e0(k >> 1) + (k & 1);
+                        const double t = (e < n && e / w == j) ? x[k] * x[k] : 0.0;
+                        acc = (k == 0) ? t : acc + t;
+                    }
+                    cj[j] = acc;
+                }
+            }
+            double r2[2] = {r[0], r[1]};
+            R.run(r2);
+            double *cxs = lds + L_CX;
+            __syncthreads(); // readers of the previous trial's c(x) are done
+#pragma unroll
+            for (int j0 = 0; j0 < FL_MAX_CONSTRAINTS; j0 += 4) { // reduce the constraints four at a time
+                if (j0 < m) {
+                    double q[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) q[u] = cj[j0 + u];
+                    R.run(q);
+                    if (threadIdx.x == 0) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) cxs[j0 + u] = q[u] - 1.0;
+                    }
+                }
+            }
+            __syncthreads();
+            // L = f - lambda.c + miu/2 c.c (NO.f90:2198); v = miu*c - lambda (NO.f90:2205)
+            double lc = 0.0, c2 = 0.0;
+            for (int j = 0; j < m; ++j) {
+                lc = lc + lds[L_LAM + j] * cxs[j];
+                c2 = c2 + cxs[j] * cxs[j];
+            }
+            f = uni(Obj::combine(r2[0], r2[1]) - lc + miu / 2.0 * c2);
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+                const int e = G::e0(k >> 1) + (k & 1);
+                if (e < n) {
+                    const int j = e / w;
+                    const double v = miu * cxs[j] - lds[L_LAM + j];
+                    g[k] = g[k] + (2.0 * x[k]) * v; // Ldx=Ldx+matmul(cdx,miu*cx-lambda)
+                }
+            }
+            double q2[2] = {dot_part<EPT>(g, p), dot_part<EPT>(g, g)};
+            R.run(q2);
+            gp = uni(q2[0]);
+            ggo = uni(q2[1]);
+        } else {
+            r[2] = dot_part<EPT>(g, p);
+            r[3] = dot_part<EPT>(g, g);
+            R.run(r);
+            f = uni(Obj::combine(r[0], r[1]));
+            gp = uni(r[2]);
+            ggo = uni(r[3]);
+        }
+    }
+
+    // ---------------------------------------------------------------- machine
+    // Called with the result of the pending request; returns the next request (0 = finished).
+    __device__ __forceinline__ int advance(double fv, double pv, double gg_new)
+    {
+        nf += (pending & FL_REQ_F) ? 1 : 0;
+        ng += (pending & FL_REQ_G) ? 1 : 0;
+        int rq;
+        if (phase == PH_INIT) {
+            rq = after_init(fv, gg_new);
+        } else {
+            gg = gg_new;
+            rq = __builtin_amdgcn_readfirstlane(ls.step(fv, pv));
+            ls.uniformize();
+            if (rq == 0) rq = after_linesearch();
+        }
+        pending = rq;
+        return rq;
+    }
+    __device__ __forceinline__ double request_point() const { return ls.a_eval; }
+
+    __device__ __forceinline__ int begin_linesearch()
+    {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) x0[k] = x[k]; // xold=x (doubles as the line search's x0)
+        if constexpr (NEEDS_G0) store_pad<NW, EPT>(lds + L_G0, g); // fdold=fdnew, parked in LDS
+        phidold = phid;
+        // the *_fdwithf searchers only in main loops with f_fd present; the first search of L-BFGS / BFGS
+        // and L-BFGS' pre-iterations never use f_fd (NO.f90:448-460, 486-498, 689-701)
+        int fused = A.fused;
+        if constexpr (AUG) fused = 1; // AugmentedLagrangian always passes f_fd=L_Ld (NO.f90:2153, 2161)
+        if constexpr (METHOD == FL_SOLVER_LBFGS) fused = fused && (iters >= A.mem);
+        if constexpr (METHOD == FL_SOLVER_BFGS) fused = fused && (iters >= 1);
+        const int strong = (METHOD == FL_SOLVER_CG && A.cg_method == FL_CG_PR) ? 1 : A.strong;
+        phase = PH_LS;
+        const int rq = __builtin_amdgcn_readfirstlane(ls.begin(strong, fused, A.c1, A.c2, A.incr, a, fnew, phid));
+        ls.uniformize();
+        return rq;
+    }
+
+    // initial f(x), f'(x) are in (NO.f90:87-96, 230-239, 436-445, 668-687)
+    __device__ __forceinline__ int after_init(double f, double gg0)
+    {
+        fnew = f;
+        gg = gg0;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) p[k] = -g[k];
+        phid = -gg; // p=-fdnew; phidnew=-dot_product(fdnew,fdnew)
+        pp = gg;
+        status = FL_STATUS_CONVERGED;
+        if (gg < A.tol) return inner_finished(); // if(-phidnew<tol) return
+        a = uni((fnew == 0.0) ? 1.0 : fabs(fnew) / sqrt(gg));
+        status = FL_STATUS_MAXIT;
+        if (max_linesearches() <= 0) return inner_finished();
+        return begin_linesearch();
+    }
+    __device__ __forceinline__ int max_linesearches() const
+    {
+        // L-BFGS: 1 + (mem-1) pre-iterations + maxit; BFGS (ExactStep<=0): first step + maxit; SD/CG: maxit
+        if constexpr (METHOD == FL_SOLVER_LBFGS) return A.mem + A.maxit;
+        if constexpr (METHOD == FL_SOLVER_BFGS) return 1 + A.maxit;
+        return A.maxit;
+    }
+
+    // the line search returned: convergence tests on the new gradient, then the new direction
+    __device__ __forceinline__ int after_linesearch()
+    {
+        a = ls.a;
+        fnew = ls.fx;
+        ++iters;
+        if (gg < A.tol) { // NO.f90:174, 355, 612, 998
+            status = FL_STATUS_CONVERGED;
+            return inner_finished();
+        }
+        if (pp * a * a < A.minstep) { // "step length has converged"
+            status = FL_STATUS_STEP_CONVERGED;
+            return inner_finished();
+        }
+        if (iters >= max_linesearches()) {
+            status = FL_STATUS_MAXIT;
+            return inner_finished();
+        }
+        double g0[EPT];
+        if constexpr (NEEDS_G0) load_pad<NW, EPT>(lds + L_G0, g0);
+        if constexpr (METHOD == FL_SOLVER_SD) { // NO.f90:185-186
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) p[k] = -g[k];
+            phid = -gg;
+            pp = gg;
+            a = a * phidold / phid;
+        } else if constexpr (METHOD == FL_SOLVER_CG) {
+            direction_cg(g0);
+        } else if constexpr (METHOD == FL_SOLVER_LBFGS) {
+            direction_lbfgs(g0);
+        } else {
+            direction_bfgs(g0);
+        }
+        phid = uni(phid);
+        pp = uni(pp);
+        a = uni(a);
+        return begin_linesearch();
+    }
+
+    // inner solver returned; with AUG run the outer update (NO.f90:2155-2157), else finish
+    __device__ __forceinline__ int inner_finished()
+    {
+        if constexpr (AUG) {
+            // call c(cx,x,M,N): cx of the last evaluation is c(x) (x is the last evaluated point)
+            const int m = A.aug_m;
+            double *cxs = lds + L_CX;
+            double c2 = 0.0;
+            for (int j = 0; j < m; ++j) c2 = c2 + cxs[j] * cxs[j];
+            cc = uni(c2);
+            ++outer_it;
+            inner_iters_total += iters;
+            iters = 0;
+            const double tolsq = A.precision * A.precision;
+            if (c2 < tolsq) { // if(dot_product(cx,cx)<tolsq) exit
+                status = FL_STATUS_CONVERGED;
+                phase = PH_DONE;
+                return 0;
+            }
+            __syncthreads();
+            if ((int)threadIdx.x < m) // lambda=lambda-miu*cx
+                lds[L_LAM + threadIdx.x] = lds[L_LAM + threadIdx.x] - miu * cxs[threadIdx.x];
+            __syncthreads();
+            miu = uni(miu * A.incr); // miu=miu*incrmt
+            if (outer_it >= A.maxit) { // do iIteration=1,maxit exhausted
+                status = FL_STATUS_MAXIT;
+                phase = PH_DONE;
+                return 0;
+            }
+            // fresh inner solve from the current x: every solver starts with an evaluation of L, L'
+            recent = -1;
+            cnt = 0;
+            phase = PH_INIT;
+            return FL_REQ_F | FL_REQ_G | FL_REQ_NOMOVE;
+        } else {
+            phase = PH_DONE;
+            return 0;
+        }
+    }
+
+    // ---------------------------------------------------------------- directions
+    __device__ __forceinline__ void direction_cg(const double (&g0)[EPT])
+    {
+        double yk[EPT];
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) yk[k] = g[k] - g0[k];
+        double beta;
+        if (A.cg_method == FL_CG_DY) { // p=-g+(g.g)/((g-gold).p)*p, NO.f90:366
+            double q[1] = {dot_part<EPT>(yk, p)};
+            R.run(q);
+            beta = gg / q[0];
+        } else { // p=-g+(g.(g-gold))/(gold.gold)*p, NO.f90:387
+            double q[2] = {dot_part<EPT>(g, yk), dot_part<EPT>(g0, g0)};
+            R.run(q);
+            beta = q[0] / q[1];
+        }
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) p[k] = -g[k] + beta * p[k];
+        double q2[2] = {dot_part<EPT>(g, p), dot_part<EPT>(p, p)};
+        R.run(q2);
+        phid = q2[0];
+        pp = q2[1];
+        if (phid > 0.0) { // ascent direction: reset to steepest descent, NO.f90:368-370
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) p[k] = -g[k];
+            phid = -gg;
+            pp = gg;
+        }
+        a = a * phidold / phid;
+    }
+
+    __device__ __forceinline__ void direction_lbfgs(const double (&g0)[EPT])
+    {
+        double *hist = hist_base();
+        double *rho_s = lds + L_RHO, *alpha_s = lds + L_ALPHA;
+        const int mem = A.mem;
+        recent = (recent + 1 == mem) ? 0 : recent + 1; // recent=mod(recent+1,mem)
+        if (cnt < mem) ++cnt;
+        double r[2];
+        {
+            double sv[EPT], yv[EPT];
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+                sv[k] = x[k] - x0[k];
+                yv[k] = g[k] - g0[k];
+            }
+            store_pad<NW, EPT>(hist + (size_t)(2 * recent) * NPAD, sv);
+            store_pad<NW, EPT>(hist + (size_t)(2 * recent + 1) * NPAD, yv);
+            r[0] = dot_part<EPT>(yv, sv);
+            r[1] = dot_part<EPT>(yv, yv);
+        }
+        R.run(r);
+        if (threadIdx.x == 0) rho_s[recent] = 1.0 / r[0]; // rho=1/(y.s): no curvature safeguard (NO.f90:623)
+        rho_recent = uni(1.0 / r[0]);
+        yy_recent = uni(r[1]);
+        __syncthreads();
+
+        // Before(): two-loop recursion, newest -> oldest, then oldest -> newest (NO.f90:586-608).
+        // p = g in registers; the ring streams from HBM with the next step's rows in flight.
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) p[k] = g[k];
+        double sA[EPT], yA[EPT], sB[EPT], yB[EPT];
+        auto slot_of = [&](int j) { // j-th newest
+            int s = recent - j;
+            return s < 0 ? s + mem : s;
+        };
+        auto fetch = [&](int j, double (&s_)[EPT], double (&y_)[EPT]) {
+            const double *row = hist + (size_t)(2 * slot_of(j)) * NPAD;
+            load_pad<NW, EPT>(row, s_);
+            load_pad<NW, EPT>(row + NPAD, y_);
+        };
+        auto down = [&](int j, const double (&s_)[EPT], const double (&y_)[EPT]) {
+            const int sl = slot_of(j);
+            double q[1] = {dot_part<EPT>(s_, p)};
+            R.run(q);
+            const double al = rho_s[sl] * q[0]; // alpha(i)=rho(i)*dot_product(s(:,i),p)
+            if (threadIdx.x == 0) alpha_s[sl] = al;
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) p[k] = p[k] - al * y_[k];
+        };
+        auto upw = [&](int j, const double (&s_)[EPT], const double (&y_)[EPT]) {
+            const int sl = slot_of(j);
+            double q[1] = {dot_part<EPT>(y_, p)};
+            R.run(q);
+            const double be = rho_s[sl] * q[0]; // phidnew=rho(i)*dot_product(y(:,i),p)
+            const double co = alpha_s[sl] - be;
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) p[k] = p[k] + co * s_[k];
+        };
+        fetch(0, sA, yA);
+        for (int j = 0; j < cnt; j += 2) {
+            if (j + 1 < cnt) fetch(j + 1, sB, yB);
+            down(j, sA, yA);
+            if (j + 1 < cnt) {
+                if (j + 2 < cnt) fetch(j + 2, sA, yA);
+                down(j + 1, sB, yB);
+            }
+        }
+        fetch(cnt - 1, sA, yA); // oldest pair first on the way back: start its loads before the scaling
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) p[k] = p[k] / rho_recent / yy_recent; // p=p/rho(recent)/(y.y)
+        __syncthreads(); // alpha_s written by thread 0 is visible (NW == 1 has no reduction barrier)
+        for (int j = cnt - 1; j >= 0; j -= 2) {
+            if (j - 1 >= 0) fetch(j - 1, sB, yB);
+            upw(j, sA, yA);
+            if (j - 1 >= 0) {
+                if (j - 2 >= 0) fetch(j - 2, sA, yA);
+                upw(j - 1, sB, yB);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) p[k] = -p[k];
+        r[0] = dot_part<EPT>(g, p);
+        r[1] = dot_part<EPT>(p, p);
+        R.run(r);
+        phid = r[0]; // phidnew=dot_product(fdnew,p)
+        pp = r[1];
+        a = 1.0;
+    }
+
+    // BFGS without exact Hessian (ExactStep <= 0): rank-2 update of the inverse Hessian in its
+    // O(n^2) form, H' = H - rho q s^T - rho s q^T + (rho^2 y.q + rho) s s^T, q = H y, which is
+    // algebraically U^T (H U) + rho s s^T with U = I - rho y s^T (NO.f90:1010-1014; first step
+    // H = a I, NO.f90:711-715).  Two streaming passes over the column-major H [n][NPAD]:
+    //   pass 1: q = H y           (reads 8 n^2 B; "axpy" form, no reductions: q_i sums over j in order)
+    //   pass 2: H' written in place while p = -H' g accumulates (reads + writes 16 n^2 B)
+    __device__ __forceinline__ void direction_bfgs(const double (&g0)[EPT])
+    {
+        double *H = hist_base();
+        double *bs = lds + L_BF, *bq = bs + NPAD, *bg = bq + NPAD;
+        const bool first = (iters == 1);
+        double sv[EPT], yv[EPT], q[EPT];
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            sv[k] = x[k] - x0[k]; // s=x-s
+            yv[k] = g[k] - g0[k]; // y=fdnew-y
+        }
+        double r1[1] = {dot_part<EPT>(yv, sv)};
+        R.run(r1);
+        const double rho = uni(1.0 / r1[0]); // rho=1d0/dot_product(y,s)
+        __syncthreads();
+        store_pad<NW, EPT>(bs, yv); // y broadcast for pass 1
+        __syncthreads();
+        if (first) {
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) q[k] = a * yv[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) q[k] = 0.0;
+            for (int j = 0; j < n; j += BF_UNROLL) {
+                double h[BF_UNROLL][EPT];
+#pragma unroll
+                for (int u = 0; u < BF_UNROLL; ++u)
+                    if (j + u < n) load_pad<NW, EPT>(H + (size_t)(j + u) * NPAD, h[u]);
+#pragma unroll
+                for (int u = 0; u < BF_UNROLL; ++u) {
+                    if (j + u < n) {
+                        const double yj = bs[j + u];
+#pragma unroll
+                        for (int k = 0; k < EPT; ++k) q[k] = q[k] + h[u][k] * yj;
+                    }
+                }
+            }
+        }
+        double r2[1] = {dot_part<EPT>(yv, q)};
+        R.run(r2);
+        const double cs = uni(rho * rho * r2[0] + rho);
+        __syncthreads();
+        store_pad<NW, EPT>(bs, sv);
+        store_pad<NW, EPT>(bq, q);
+        store_pad<NW, EPT>(bg, g);
+        __syncthreads();
+        double rq_[EPT], rs_[EPT], cs_[EPT], acc[EPT];
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            rq_[k] = rho * q[k];
+            rs_[k] = rho * sv[k];
+            cs_[k] = cs * sv[k];
+            acc[k] = 0.0;
+        }
+        for (int j = 0; j < n; j += BF_UNROLL) {
+            double h[BF_UNROLL][EPT];
+#pragma unroll
+            for (int u = 0; u < BF_UNROLL; ++u) {
+                if (j + u < n) {
+                    if (first) {
+#pragma unroll
+                        for (int k = 0; k < EPT; ++k)
+                            h[u][k] = (G::e0(k >> 1) + (k & 1) == j + u) ? a : 0.0;
+                    } else {
+                        load_pad<NW, EPT>(H + (size_t)(j + u) * NPAD, h[u]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < BF_UNROLL; ++u) {
+                if (j + u < n) {
+                    const double sj = bs[j + u], qj = bq[j + u], gj = bg[j + u];
+#pragma unroll
+                    for (int k = 0; k < EPT; ++k) {
+                        const double hn = h[u][k] - rq_[k] * sj - rs_[k] * qj + cs_[k] * sj;
+                        h[u][k] = hn;
+                        acc[k] = acc[k] + hn * gj;
+                    }
+                    store_pad<NW, EPT>(H + (size_t)(j + u) * NPAD, h[u]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) p[k] = -acc[k]; // p=-matmul(H,fdnew)
+        double r3[2] = {dot_part<EPT>(g, p), dot_part<EPT>(p, p)};
+        R.run(r3);
+        phid = r3[0];
+        pp = r3[1];
+        a = 1.0;
+    }
+
+    // ---------------------------------------------------------------- outputs
+    __device__ __forceinline__ void finish()
+    {
+        store_user<NW, EPT>(A.x + (size_t)prob * n, n, x);
+        if constexpr (AUG) {
+            __syncthreads();
+            if ((int)threadIdx.x < A.aug_m)
+                A.lambda[(size_t)prob * A.aug_m + threadIdx.x] = lds[L_LAM + threadIdx.x];
+        }
+        if (threadIdx.x == 0) {
+            if (A.f_out) A.f_out[prob] = fnew;
+            if (A.gg_out) A.gg_out[prob] = gg;
+            if (A.iters) A.iters[prob] = iters + inner_iters_total;
+            if (A.status) A.status[prob] = status;
+            if (A.nf) A.nf[prob] = nf;
+            if (A.ng) A.ng[prob] = ng;
+            if constexpr (AUG) {
+                if (A.outer) A.outer[prob] = outer_it;
+                if (A.cnorm2) A.cnorm2[prob] = cc;
+            }
+        }
+    }
+};
+
+} // namespace fl

@@ -80,6 +80,7 @@ typedef struct fl_options {
 #define FL_SOLVER_SD 0
 #define FL_SOLVER_CG 1
 #define FL_SOLVER_LBFGS 2
+#define FL_SOLVER_BFGS 3
 
 int fl_version(void);
 void fl_default_options(fl_options *opt, int solver);
@@ -91,8 +92,9 @@ void fl_default_options(fl_options *opt, int solver);
  * is too large for the on-chip path. */
 int fl_reduction_geometry(int n, int *threads, int *ept);
 
-/* Bytes of device workspace fl_lbfgs_batched needs (the (s,y) history ring,
- * [batch][2*memory][padded n] fp64).  0 for SD / CG. */
+/* Bytes of device workspace: FL_SOLVER_LBFGS -- the (s,y) history ring,
+ * [batch][2*memory][padded n] fp64; FL_SOLVER_BFGS -- the inverse Hessians [batch][n][padded n];
+ * 0 for SD / CG. */
 size_t fl_workspace_bytes(int solver, int batch, int n, int memory);
 
 /* Batched solvers.  x_dev [batch][n] in/out (initial guess -> minimiser);
@@ -113,6 +115,37 @@ int fl_steepest_descent_batched(int objective, int batch, int n, double *x_dev, 
                                 const double *b_dev, const fl_options *opt, double *f_dev, double *gg_dev,
                                 int32_t *iters_dev, int32_t *status_dev, int32_t *nf_dev, int32_t *ng_dev,
                                 void *stream);
+
+/* Dense BFGS without exact Hessian -- the reference's ExactStep <= 0 path (subroutine BFGS,
+ * NO.f90:632-1022: first step 683-716, After_NoHessian 996-1015; C++ binding
+ * cpp/NonlinearOptimization.hpp:326-342).  The inverse-Hessian update
+ * H <- U^T (H U) + rho s s^T, U = I - rho y s^T (NO.f90:1010-1013) is evaluated in its
+ * algebraically equal rank-2 form, H - rho q s^T - rho s q^T + (rho^2 y.q + rho) s s^T with q = H y,
+ * as two streaming passes over H (24 n^2 bytes per iteration instead of 4 n^3 flops).
+ * workspace: the column-major inverse Hessians, fl_workspace_bytes(FL_SOLVER_BFGS, batch, n, 0)
+ * = batch * n * npad * 8 bytes.  max_iteration bounds the main loop (one more search
+ * precedes it, NO.f90:689-701). */
+int fl_bfgs_batched(int objective, int batch, int n, double *x_dev, const double *d_dev, const double *b_dev,
+                    const fl_options *opt, void *workspace_dev, size_t workspace_bytes, double *f_dev, double *gg_dev,
+                    int32_t *iters_dev, int32_t *status_dev, int32_t *nf_dev, int32_t *ng_dev, void *stream);
+
+/* Augmented Lagrangian for equality constraints (subroutine AugmentedLagrangian, NO.f90:2005-2241;
+ * C++ binding cpp/NonlinearOptimization.hpp:367-392) around solver = FL_SOLVER_LBFGS (NO.f90:2150-2167)
+ * or FL_SOLVER_CG (NO.f90:2168-2185).  Built-in constraint family: m block spheres
+ * c_j(x) = sum_{i in block j} x_i^2 - 1 over m consecutive blocks of n/m elements (m = 1 is the unit
+ * sphere of the reference's test, test/test.f90:699-721); m <= 16, n % m == 0.
+ * lambda_dev [batch][m] in/out (lambda0 -> final multipliers), miu0 as the reference (clamped to >= 1).
+ * As in the reference, opt->precision is both the inner gradient tolerance and the outer ||c||
+ * tolerance, opt->max_iteration bounds outer and inner loops, opt->increment is both the line-search
+ * growth factor and the miu growth factor, and the inner solver always runs with f_fd present.
+ * Outputs: f_dev = augmented Lagrangian at exit, cnorm2_dev = c.c at exit, iters_dev = inner
+ * iterations (all outer rounds), outer_dev = outer iterations, status_dev = FL_STATUS_CONVERGED
+ * (||c|| < Precision) or FL_STATUS_MAXIT, nf/ng = objective / gradient evaluations. */
+int fl_augmented_lagrangian_batched(int solver, int objective, int batch, int n, int m, double *x_dev,
+                                    const double *d_dev, const double *b_dev, double *lambda_dev, double miu0,
+                                    const fl_options *opt, void *workspace_dev, size_t workspace_bytes, double *f_dev,
+                                    double *cnorm2_dev, int32_t *iters_dev, int32_t *outer_dev, int32_t *status_dev,
+                                    int32_t *nf_dev, int32_t *ng_dev, void *stream);
 
 /* The L-BFGS two-loop recursion alone (Before(), NO.f90:586-608) for a batch:
  * p = -H_k g from a full ring of `memory` pairs.  hist_dev is the solver's

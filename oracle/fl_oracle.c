@@ -745,9 +745,9 @@ static void bfgs_update(int n, double *H, double *U, const double *s, const doub
         if (first) {
             for (int i = 0; i < n; ++i) q[i] = a * y[i];
         } else {
-            for (int i = 0; i < n; ++i) { /* q_i = sum_k H(k,i) y_k : column i, sequential in k */
+            for (int i = 0; i < n; ++i) { /* q_i = sum_k H(i,k) y_k, sequential in k (H column-major) */
                 double v = 0.0;
-                for (int k = 0; k < n; ++k) v = v + H[i * N + k] * y[k];
+                for (int k = 0; k < n; ++k) v = v + H[k * N + i] * y[k];
                 q[i] = v;
             }
         }

@@ -230,3 +230,133 @@ def test_two_loop_kernel_matches_solver_direction():
             be = rho[k, i] * Y[k, i].dot(q)
             q += (al[i] - be) * S[k, i]
         assert np.allclose(p[k].cpu().numpy(), -q, rtol=1e-9, atol=1e-12)
+
+
+# ------------------------------------------------------------------ dense BFGS (ExactStep <= 0)
+def _gpu_bfgs(kind, x0, d=None, b=None, **kw):
+    NLO = _nlo()
+    dev = torch.device("cuda:0")
+    x = torch.tensor(np.atleast_2d(x0), dtype=torch.float64, device=dev).contiguous()
+    dd = torch.tensor(np.broadcast_to(d, x.shape).copy(), device=dev) if d is not None else None
+    bb = torch.tensor(np.broadcast_to(b, x.shape).copy(), device=dev) if b is not None else None
+    out = NLO.BFGS(kind, x, dd, bb, **kw)
+    torch.cuda.synchronize()
+    res = {k: v.cpu().numpy() for k, v in out.items() if k != "workspace"}
+    res["x"] = x.cpu().numpy()
+    return res
+
+
+def _oracle_bfgs(kind, x0, d, b, form, mode, kw):
+    NLO = _nlo()
+    n = np.atleast_2d(x0).shape[1]
+    T, E = NLO.reduction_geometry(n)
+    o = _oracle_opts(O.BFGS, kw)
+    o.exact_step = 0
+    return O.solve_batch(O.BFGS, kind, x0, d=d, b=b, opts=o, use_ffd=bool(kw.get("f_fd", False)), bfgs_form=form,
+                         sum_mode=mode, threads=T, ept=E)
+
+
+@pytest.mark.parametrize("kind,n,kw", [(O.QUARTIC, 10, {}), (O.ROSENBROCK, 10, {}), (O.ROSENBROCK, 10, {"f_fd": True}),
+                                       (O.ROSENBROCK, 10, {"Strong": False}), (O.ROSENBROCK, 7, {}),
+                                       (O.ROSENBROCK, 130, {"MaxIteration": 150}), (O.DIAGQUAD, 96, {}),
+                                       (O.DIAGQUAD, 300, {"MaxIteration": 100}), (O.ROSENBROCK, 600, {"MaxIteration": 40}),
+                                       (O.DIAGQUAD, 1100, {"MaxIteration": 12}), (O.ROSENBROCK, 2100, {"MaxIteration": 6})])
+def test_bfgs_rank2_streaming_update_bitexact(kind, n, kw):
+    """GPU BFGS == oracle BFGS with the same rank-2 algebra (update_form 1), bit for bit, all geometries"""
+    rng = np.random.default_rng(n)
+    B = 3 if n < 1000 else 2
+    if kind == O.ROSENBROCK:
+        x0 = np.full((B, n), -1.2) if n == 10 else 1.0 + 0.1 * rng.uniform(-1, 1, (B, n))
+        if n == 10:
+            x0[:, 1::2] = 1.0
+            x0[1:] += 0.01 * rng.standard_normal((B - 1, n))
+        d = b = None
+    elif kind == O.QUARTIC:
+        x0, d, b = np.vstack([0.1 * np.arange(1, n + 1), rng.random((B - 1, n))]), None, None
+    else:
+        d, b = _quads(B, n, 10.0, 300.0, n)
+        x0 = np.zeros((B, n))
+    g = _gpu_bfgs(kind, x0, d, b, **kw)
+    o = _oracle_bfgs(kind, x0, d, b, 1, O.TREE, kw)
+    _assert_bitexact(g, o)
+
+
+def test_bfgs_config1_matches_reference_two_matmul_form():
+    """BASELINE.json config 1: Rosenbrock n=10, BFGS (ExactStep=0), standard start.  The reference's own
+    arithmetic (two dense matmuls, sequential sums -- pinned in test_oracle_pins.py: f=0, x=1 exactly)
+    against the GPU's rank-2 form: same minimiser within the north-star tolerance."""
+    x0 = np.full((1, 10), -1.2)
+    x0[:, 1::2] = 1.0
+    g = _gpu_bfgs(O.ROSENBROCK, x0)
+    o = _oracle_bfgs(O.ROSENBROCK, x0, None, None, 0, O.SEQ, {})
+    assert o["f"][0] == 0.0 and np.all(o["x"] == 1.0)
+    assert g["status"][0] in (O.CONVERGED, O.STEP_CONVERGED)
+    assert abs(g["f"][0] - o["f"][0]) <= 1e-20
+    assert np.linalg.norm(g["x"] - o["x"]) <= 1e-8 * np.linalg.norm(o["x"])
+    # quartic of test/test.f90:390-413 (BFGS with ExactStep=0): "should print close to 0"
+    xq = 0.1 * np.arange(1, 11)[None, :]
+    g = _gpu_bfgs(O.QUARTIC, xq)
+    assert np.linalg.norm(g["x"]) < 1e-4
+
+
+# ------------------------------------------------------------------ augmented Lagrangian
+def _gpu_auglag(solver_name, kind, x0, m, d=None, b=None, miu0=1.0, **kw):
+    NLO = _nlo()
+    dev = torch.device("cuda:0")
+    x = torch.tensor(np.atleast_2d(x0), dtype=torch.float64, device=dev).contiguous()
+    dd = torch.tensor(np.broadcast_to(d, x.shape).copy(), device=dev) if d is not None else None
+    bb = torch.tensor(np.broadcast_to(b, x.shape).copy(), device=dev) if b is not None else None
+    out = NLO.AugmentedLagrangian(kind, x, m, dd, bb, UnconstrainedSolver=solver_name, miu0=miu0, **kw)
+    torch.cuda.synchronize()
+    res = {k: v.cpu().numpy() for k, v in out.items() if k != "workspace"}
+    res["x"] = x.cpu().numpy()
+    return res
+
+
+@pytest.mark.parametrize("solver_name,solver,kind,n,m,kw", [
+    ("LBFGS", O.LBFGS, O.QUARTIC, 10, 1, {}),                      # test/test.f90:452-478: unit sphere, dim 10
+    ("ConjugateGradient", O.CG, O.QUARTIC, 10, 1, {}),
+    ("LBFGS", O.LBFGS, O.DIAGQUAD, 64, 8, {"Precision": 1e-10}),
+    ("LBFGS", O.LBFGS, O.DIAGQUAD, 512, 8, {"Precision": 1e-10}),  # BASELINE.json config 5 shape
+    ("ConjugateGradient", O.CG, O.DIAGQUAD, 512, 8, {"Precision": 1e-8, "MaxIteration": 200}),
+    ("LBFGS", O.LBFGS, O.ROSENBROCK, 96, 3, {"Precision": 1e-9, "Memory": 5}),
+])
+def test_augmented_lagrangian_bitexact(solver_name, solver, kind, n, m, kw):
+    NLO = _nlo()
+    rng = np.random.default_rng(n + m)
+    B = 3
+    i = np.arange(1, n + 1).astype(float)
+    x0 = 0.1 + 0.05 * np.cos(i)[None, :] + 0.01 * rng.standard_normal((B, n))
+    if kind == O.QUARTIC:
+        x0 = rng.random((B, n))
+    d = b = None
+    if kind == O.DIAGQUAD:
+        d, b = _quads(B, n, 2.0, 10.0, 5)
+    g = _gpu_auglag(solver_name, kind, x0, m, d, b, **kw)
+    T, E = NLO.reduction_geometry(n)
+    oo = _oracle_opts(solver, kw)
+    o = O.auglag_batch(solver, kind, x0, m, d=d, b=b, opts=oo, sum_mode=O.TREE, threads=T, ept=E)
+    assert np.array_equal(g["outer"], o["outer"]), (g["outer"], o["outer"])
+    assert np.array_equal(g["iters"], o["iters"]), (g["iters"], o["iters"])
+    assert np.array_equal(g["nf"], o["nf"]) and np.array_equal(g["ng"], o["ng"])
+    assert np.array_equal(g["x"].view(np.uint64), o["x"].view(np.uint64))
+    assert np.array_equal(g["lambda"].view(np.uint64), o["lam"].view(np.uint64))
+    assert np.array_equal(g["cnorm2"].view(np.uint64), o["cnorm2"].view(np.uint64))
+    if kind == O.QUARTIC:  # the reference test's criterion: norm2(x) - 1 close to 0
+        assert np.all(np.abs(np.linalg.norm(g["x"], axis=1) - 1.0) < 1e-6)
+
+
+def test_augmented_lagrangian_config5_vs_reference_order():
+    """N=512, M=8 block spheres, the survey's probe problem (pinned in test_oracle_pins.py:
+    f=-23.331108193268726): GPU result vs the oracle in the reference's summation order."""
+    n, m = 512, 8
+    i = np.arange(1, n + 1).astype(float)
+    d = (1 + 9 * (i - 1) / (n - 1))[None, :]
+    b = np.sin(i)[None, :]
+    x0 = (0.1 + 0.05 * np.cos(i))[None, :]
+    g = _gpu_auglag("LBFGS", O.DIAGQUAD, x0, m, d, b, Precision=1e-10)
+    fx = 0.5 * np.sum(d * g["x"] ** 2) - np.sum(b * g["x"])
+    assert g["status"][0] == O.CONVERGED and np.sqrt(g["cnorm2"][0]) < 1e-10
+    assert abs(fx - (-23.331108193268726)) <= 1e-10 * 23.33
+    o = O.auglag_batch(O.LBFGS, O.DIAGQUAD, x0, m, d=d, b=b, opts=O.defaults(precision=1e-10))
+    assert np.linalg.norm(g["x"] - o["x"]) <= 1e-8 * np.linalg.norm(o["x"])
