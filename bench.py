@@ -115,12 +115,7 @@ def main():
     x = torch.empty_like(x0)
     ws = NLO.workspace(B, n, m, dev)
     opts = NLO.default_options(NLO.LBFGS_, **opt_kw)
-    gather_bufs = None
-    if world > 1 and rank == 0:
-        gather_bufs = dict(x=[torch.empty_like(x) for _ in range(world)],
-                           f=[torch.empty(B, dtype=torch.float64, device=dev) for _ in range(world)],
-                           it=[torch.empty(B, dtype=torch.int32, device=dev) for _ in range(world)],
-                           st=[torch.empty(B, dtype=torch.int32, device=dev) for _ in range(world)])
+    from FortranLibrary import distributed as D
 
     ev = []
 
@@ -134,10 +129,7 @@ def main():
         if record:
             ev.append((e0, e1))
         if world > 1:  # the single exchange of the path: converged results to rank 0 over xGMI
-            dist.gather(x, gather_bufs["x"] if rank == 0 else None, dst=0)
-            dist.gather(out["f"], gather_bufs["f"] if rank == 0 else None, dst=0)
-            dist.gather(out["iters"], gather_bufs["it"] if rank == 0 else None, dst=0)
-            dist.gather(out["status"], gather_bufs["st"] if rank == 0 else None, dst=0)
+            D.gather_results({"x": x, "f": out["f"], "iters": out["iters"], "status": out["status"]}, dst=0)
         return out
 
     def sync():

@@ -11,6 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def library_path():
+    if os.environ.get("FL_LIBRARY"):  # explicit override (tuning builds)
+        return os.environ["FL_LIBRARY"]
     cand = os.path.join(os.path.dirname(_HERE), "lib", "libFL.so")
     return cand if os.path.exists(cand) else "libFL.so"
 

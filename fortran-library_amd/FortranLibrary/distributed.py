@@ -1,0 +1,32 @@
+"""Sharding of a batch of independent problems over the GPUs of one node, and the single exchange
+of the path: one gather of the converged results to rank 0 (RCCL over xGMI when the process group is
+"nccl"; "gloo" in the CPU tests).  Problems are independent, so there is no
+collective inside a solve -- each rank owns a contiguous block of the batch.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(batch, rank, world):
+    """Contiguous block [lo, hi) of a global batch owned by `rank`: ceil(batch/world) problems per rank."""
+    per = -(-batch // world)
+    lo = min(batch, rank * per)
+    return lo, min(batch, lo + per)
+
+
+def gather_results(results, dst=0, group=None):
+    """Gather a dict of equally shaped per-rank tensors (x*, f*, iterations, status ...) to rank `dst`.
+
+    Returns {name: tensor concatenated over ranks along dim 0} on dst, None elsewhere.  One
+    torch.distributed.gather per array -- the only communication of the whole job.
+    """
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    out = {} if rank == dst else None
+    for name in sorted(results):
+        t = results[name].contiguous()
+        bufs = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
+        dist.gather(t, bufs, dst=dst, group=group)
+        if rank == dst:
+            out[name] = torch.cat(bufs, dim=0)
+    return out

@@ -67,10 +67,22 @@ struct LineSearch {
     }
     FL_HD void uniformize()
     {
-        c1 = uni(c1); c2abs = uni(c2abs); incr = uni(incr); fx0 = uni(fx0); phid0 = uni(phid0);
+        // Measured on the north-star workload (profiles/r01/geometry_ab.txt): pinning the whole
+        // machine pushes the kernel over the SGPR budget and the spills (v_readlane) cost more
+        // than the occupancy gains: level 0 = 25.8, 1 = 23.4, 2 = 23.0 M it/s.
+#ifndef FL_UNI_LEVEL
+#define FL_UNI_LEVEL 0
+#endif
+#if FL_UNI_LEVEL >= 1 // the values every trial touches
+        c2abs = uni(c2abs); fx0 = uni(fx0); phid0 = uni(phid0);
         a = uni(a); aold = uni(aold); fx = uni(fx); fold = uni(fold); phidnew = uni(phidnew); phidold = uni(phidold);
+        a_eval = uni(a_eval);
+#endif
+#if FL_UNI_LEVEL >= 2 // zoom's bracket and the constants
+        c1 = uni(c1); incr = uni(incr);
         low = uni(low); up = uni(up); flow = uni(flow); fup = uni(fup); phidlow = uni(phidlow); phidup = uni(phidup);
-        plma = uni(plma); a_eval = uni(a_eval);
+        plma = uni(plma);
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
         st = __builtin_amdgcn_readfirstlane(st);
         zret = __builtin_amdgcn_readfirstlane(zret);

@@ -49,7 +49,10 @@ static bool select_geometry(int n, GeoSel &g)
     if (n <= 128) g = {1, 2};
     else if (n <= 256) g = {1, 4};
     else if (n <= 512) g = {2, 4};
-    else if (n <= 1024) g = {4, 4};
+#ifdef FL_BENCH_NW
+    else if (n <= 1024) g = {FL_BENCH_NW, FL_BENCH_EPT};
+#endif
+    else if (n <= 1024) g = {2, 8}; // measured: 2x8 27.7, 4x4 25.7, 8x2 12.4 M it/s (profiles/r01/geometry_ab.txt)
     else if (n <= 2048) g = {4, 8};
     else if (n <= 4096) g = {8, 8};
     else return false;
@@ -84,12 +87,20 @@ template <int NW, int EPT> static hipError_t launch_o(int obj, int method, int a
 }
 static hipError_t launch(const GeoSel &g, int obj, int method, int aug, const SolveArgs &A, hipStream_t st)
 {
+#ifdef FL_ONLY_BENCH // tuning builds (tools/variants.sh): only the bench.py instantiation
+#ifndef FL_BENCH_NW
+#define FL_BENCH_NW 4
+#define FL_BENCH_EPT 4
+#endif
+    return launch_k<FL_BENCH_NW, FL_BENCH_EPT, FL_OBJ_DIAGQUAD, FL_SOLVER_LBFGS, 0>(A, st);
+#else
     if (g.nw == 1 && g.ept == 2) return launch_o<1, 2>(obj, method, aug, A, st);
     if (g.nw == 1 && g.ept == 4) return launch_o<1, 4>(obj, method, aug, A, st);
     if (g.nw == 2 && g.ept == 4) return launch_o<2, 4>(obj, method, aug, A, st);
-    if (g.nw == 4 && g.ept == 4) return launch_o<4, 4>(obj, method, aug, A, st);
+    if (g.nw == 2 && g.ept == 8) return launch_o<2, 8>(obj, method, aug, A, st);
     if (g.nw == 4 && g.ept == 8) return launch_o<4, 8>(obj, method, aug, A, st);
     return launch_o<8, 8>(obj, method, aug, A, st);
+#endif
 }
 
 struct AugArgs {

@@ -29,7 +29,7 @@ def test_c_abi_library_exports_every_declared_symbol():
         assert hasattr(lib, nme), nme
     assert lib.fl_version() >= 100
     t, e = C.c_int(), C.c_int()
-    for n, (T, E) in {10: (64, 2), 256: (64, 4), 512: (128, 4), 1024: (256, 4), 2048: (256, 8), 4096: (512, 8)}.items():
+    for n, (T, E) in {10: (64, 2), 256: (64, 4), 512: (128, 4), 1024: (128, 8), 2048: (256, 8), 4096: (512, 8)}.items():
         assert lib.fl_reduction_geometry(n, C.byref(t), C.byref(e)) == 0 and (t.value, e.value) == (T, E)
     assert lib.fl_reduction_geometry(100000, C.byref(t), C.byref(e)) == -2
     lib.fl_workspace_bytes.restype = C.c_size_t
