@@ -169,6 +169,13 @@ def main():
     kern_ms = sum(a.elapsed_time(bb) for a, bb in ev) / len(ev)
     achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
     status = out["status"].cpu().numpy()
+    traffic = None  # PMC-measured HBM-side bytes per launch, recorded from a separate rocprofv3 pass
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(args.workload)
+        if rec and (rec["batch_per_gpu"], rec["n"], rec["memory"]) == (B, n, m) and rec["precision"] == opts.precision:
+            traffic = rec["traffic_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
 
     res = {
         "metric": "lbfgs_iterations_per_sec",
@@ -193,7 +200,7 @@ def main():
         "converged_fraction": float((status == 0).mean()),
         "roofline": {"bound": "hbm", "kernel": "fl_solve_kernel<NW,EPT,OBJ,LBFGS> (fused solver)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": algo_bytes,
+                     "traffic": traffic, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": algo_bytes,
                      "note": "algorithmic bytes = two-loop recursion only, (4*cnt+2)*8n per iteration and problem"},
     }
 

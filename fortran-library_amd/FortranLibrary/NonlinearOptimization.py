@@ -202,6 +202,42 @@ def AugmentedLagrangian(objective, x, M, d=None, b=None, UnconstrainedSolver="LB
     return out
 
 
+FL.fl_rci_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.POINTER(Options), _vp]
+FL.fl_rci_step.argtypes = [_vp, _dp, _dp, _dp, _ip]
+FL.fl_rci_results.argtypes = [_vp, _dp, _dp, _ip, _ip, _ip, _ip]
+FL.fl_rci_destroy.argtypes = [_vp]
+
+
+def minimize_rci(solver, x, fun, options=None, max_steps=10000000, **kw):
+    """Batched minimisation of a user objective by reverse communication (fl_rci_*): `fun(x)` returns
+    (f[batch], g[batch, n]) torch CUDA tensors for the whole batch; x is updated in place.  The solver
+    machines run in the HIP kernels; only the objective is the caller's.  solver: SD | CG | LBFGS_ | BFGS_."""
+    import torch
+    o = options if options is not None else default_options(solver, **kw)
+    B, n, out = _prep(x, None, None)
+    h = C.c_void_p()
+    _check(FL.fl_rci_create(C.byref(h), solver, B, n, C.byref(o), _stream()), "fl_rci_create")
+    try:
+        req = torch.empty(B, dtype=torch.int32, device=x.device)
+        f = torch.zeros(B, dtype=torch.float64, device=x.device)
+        g = torch.zeros(B, n, dtype=torch.float64, device=x.device)
+        _check(FL.fl_rci_step(h, _ptr(x), None, None, _ptr(req)), "fl_rci_step")
+        steps = 0
+        while bool((req != 0).any()) and steps < max_steps:
+            fn, gn = fun(x)
+            f.copy_(fn)
+            g.copy_(gn)
+            _check(FL.fl_rci_step(h, _ptr(x), _ptr(f), _ptr(g), _ptr(req)), "fl_rci_step")
+            steps += 1
+        _check(FL.fl_rci_results(h, _ptr(out["f"]), _ptr(out["gg"]), _ptr(out["iters"]), _ptr(out["status"]),
+                                 _ptr(out["nf"]), _ptr(out["ng"])), "fl_rci_results")
+        torch.cuda.synchronize()
+        out["steps"] = steps
+    finally:
+        FL.fl_rci_destroy(h)
+    return out
+
+
 def two_loop(hist, rho, g, p, memory, recent):
     """Stand-alone batched two-loop recursion (Before(), NO.f90:586-608): p = -H g."""
     B, n = g.shape

@@ -216,6 +216,18 @@ template <int NW, int EPT> struct Objective<FL_OBJ_ROSENBROCK, NW, EPT> {
     __device__ __forceinline__ static double combine(double s0, double) { return s0; }
 };
 
+// objective evaluated by the caller (reverse communication, fl_rci.hip): nothing compiled in
+#define FL_OBJ_EXTERNAL 3
+template <int NW, int EPT> struct Objective<FL_OBJ_EXTERNAL, NW, EPT> {
+    static constexpr int LDS_DOUBLES = 0;
+    __device__ __forceinline__ void init(const SolveArgs &, int, double *) {}
+    __device__ __forceinline__ void eval(const double (&)[EPT], double (&)[EPT], double &s0, double &s1, int, double *)
+    {
+        s0 = s1 = 0.0;
+    }
+    __device__ __forceinline__ static double combine(double s0, double) { return s0; }
+};
+
 // ------------------------------------------------------------ the solver machine
 // METHOD: FL_SOLVER_SD | FL_SOLVER_CG | FL_SOLVER_LBFGS | FL_SOLVER_BFGS.
 // AUG = 1 wraps the objective in the augmented Lagrangian with aug_m block-sphere
@@ -734,6 +746,62 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
         phid = r3[0];
         pp = r3[1];
         a = 1.0;
+    }
+
+    // ---------------------------------------------------------------- reverse communication
+    // The machine parked in HBM between two launches of the step kernel (fl_rci.hip):
+    // sc[RCI_SCALARS] doubles, vec[3][NPAD] = p, x0, gold, rho[FL_MAX_MEMORY].
+    static constexpr int RCI_SCALARS = 48;
+    __device__ __forceinline__ void save(double *sc, double *vec, double *rho, double fv_c, double pv_c)
+    {
+        store_pad<NW, EPT>(vec, p);
+        store_pad<NW, EPT>(vec + NPAD, x0);
+        if constexpr (NEEDS_G0) {
+            double g0[EPT];
+            load_pad<NW, EPT>(lds + L_G0, g0);
+            store_pad<NW, EPT>(vec + 2 * NPAD, g0);
+        }
+        if constexpr (METHOD == FL_SOLVER_LBFGS) {
+            __syncthreads();
+            if (threadIdx.x < FL_MAX_MEMORY) rho[threadIdx.x] = lds[L_RHO + threadIdx.x];
+        }
+        if (threadIdx.x == 0) {
+            double *q = sc;
+            *q++ = fnew; *q++ = gg; *q++ = pp; *q++ = phid; *q++ = phidold; *q++ = a;
+            *q++ = yy_recent; *q++ = rho_recent; *q++ = fv_c; *q++ = pv_c;
+            *q++ = ls.c1; *q++ = ls.c2abs; *q++ = ls.incr; *q++ = ls.fx0; *q++ = ls.phid0;
+            *q++ = ls.a; *q++ = ls.aold; *q++ = ls.fx; *q++ = ls.fold; *q++ = ls.phidnew; *q++ = ls.phidold;
+            *q++ = ls.low; *q++ = ls.up; *q++ = ls.flow; *q++ = ls.fup; *q++ = ls.phidlow; *q++ = ls.phidup;
+            *q++ = ls.plma; *q++ = ls.a_eval;
+            int *iq = reinterpret_cast<int *>(sc + 32);
+            *iq++ = iters; *iq++ = nf; *iq++ = ng; *iq++ = status; *iq++ = phase; *iq++ = pending;
+            *iq++ = recent; *iq++ = cnt; *iq++ = ls.st; *iq++ = ls.zret; *iq++ = ls.fused;
+        }
+    }
+    __device__ __forceinline__ void load(const double *sc, const double *vec, const double *rho, double &fv_c,
+                                         double &pv_c)
+    {
+        load_pad<NW, EPT>(vec, p);
+        load_pad<NW, EPT>(vec + NPAD, x0);
+        if constexpr (NEEDS_G0) {
+            double g0[EPT];
+            load_pad<NW, EPT>(vec + 2 * NPAD, g0);
+            store_pad<NW, EPT>(lds + L_G0, g0);
+        }
+        if constexpr (METHOD == FL_SOLVER_LBFGS) {
+            if (threadIdx.x < FL_MAX_MEMORY) lds[L_RHO + threadIdx.x] = rho[threadIdx.x];
+            __syncthreads();
+        }
+        const double *q = sc;
+        fnew = *q++; gg = *q++; pp = *q++; phid = *q++; phidold = *q++; a = *q++;
+        yy_recent = *q++; rho_recent = *q++; fv_c = *q++; pv_c = *q++;
+        ls.c1 = *q++; ls.c2abs = *q++; ls.incr = *q++; ls.fx0 = *q++; ls.phid0 = *q++;
+        ls.a = *q++; ls.aold = *q++; ls.fx = *q++; ls.fold = *q++; ls.phidnew = *q++; ls.phidold = *q++;
+        ls.low = *q++; ls.up = *q++; ls.flow = *q++; ls.fup = *q++; ls.phidlow = *q++; ls.phidup = *q++;
+        ls.plma = *q++; ls.a_eval = *q++;
+        const int *iq = reinterpret_cast<const int *>(sc + 32);
+        iters = *iq++; nf = *iq++; ng = *iq++; status = *iq++; phase = *iq++; pending = *iq++;
+        recent = *iq++; cnt = *iq++; ls.st = *iq++; ls.zret = *iq++; ls.fused = *iq++;
     }
 
     // ---------------------------------------------------------------- outputs

@@ -1,0 +1,420 @@
+// fl_rci.hip -- reverse-communication ("ask / tell") form of the batched solvers, and on
+// top of it the reference's legacy single-problem entry points with HOST callbacks.
+//
+// The reference calls user code for every evaluation: subroutine f(fx,x,dim), fd(g,x,dim),
+// integer function f_fd(fx,g,x,dim) (NO.f90:33-38).  A GPU solver cannot call back into the
+// host from a kernel, so the machine of fl_device.hpp is parked in HBM between launches:
+//     fl_rci_step():  [take the caller's f, g at the requested points] -> advance every
+//                     problem's machine to its next request -> write the next trial points
+// The caller (host code with callbacks, or a torch / HIP objective for the whole batch)
+// evaluates exactly what request[] asks for and calls fl_rci_step again.  All vector
+// arithmetic (x0 + a p, dot products, two-loop recursion, BFGS update) runs in the kernel;
+// there is no CPU solver behind these entry points.
+//
+// Legacy symbols (cpp/NonlinearOptimization.hpp:278-393 binds them; gfortran and ifort
+// manglings): steepestdescent, conjugategradient(_basic), lbfgs, bfgs -- batch of one,
+// callbacks evaluated on the host, x copied device <-> host per evaluation.
+#include "fl_device.hpp"
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace fl {
+
+template <int NW, int EPT, int METHOD>
+__global__ __launch_bounds__(NW * 64) void rci_step_kernel(SolveArgs A, int first, double *sc_all, double *vec_all,
+                                                           double *rho_all, const double *f_dev,
+                                                           const double *g_dev, int32_t *request)
+{
+    using S = Solver<NW, EPT, FL_OBJ_EXTERNAL, METHOD, 0>;
+    __shared__ __attribute__((aligned(16))) double lds[S::LDS_TOTAL];
+    S s(A, lds);
+    const int prob = blockIdx.x, n = A.n;
+    double *sc = sc_all + (size_t)prob * S::RCI_SCALARS;
+    double *vec = vec_all + (size_t)prob * 3 * S::NPAD;
+    double *rho = rho_all + (size_t)prob * FL_MAX_MEMORY;
+    s.init(); // x = the point the caller has just evaluated (or the initial guess)
+    int rq;
+    double fv = 0.0, pv = 0.0;
+    if (first) {
+        rq = s.start();
+    } else {
+        s.load(sc, vec, rho, fv, pv);
+        if (s.phase == S::PH_DONE) {
+            if (threadIdx.x == 0) request[prob] = 0;
+            return;
+        }
+        double ggv = s.gg;
+        if (s.pending & FL_REQ_F) fv = f_dev[prob];
+        if (s.pending & FL_REQ_G) {
+            load_user<NW, EPT>(g_dev + (size_t)prob * n, n, s.g);
+            double q[2] = {dot_part<EPT>(s.g, s.p), dot_part<EPT>(s.g, s.g)};
+            s.R.run(q);
+            pv = q[0];
+            ggv = q[1];
+        }
+        rq = s.advance(fv, pv, ggv);
+    }
+    if (rq == 0) {
+        s.finish();
+    } else if (!(rq & (FL_REQ_SAME | FL_REQ_NOMOVE))) {
+        s.move(s.request_point());
+        store_user<NW, EPT>(A.x + (size_t)prob * n, n, s.x);
+    }
+    s.save(sc, vec, rho, fv, pv);
+    if (threadIdx.x == 0) request[prob] = rq;
+}
+
+struct Rci {
+    int solver, batch, n, nw, ept, first;
+    SolveArgs A;
+    double *sc, *vec, *rho, *ws, *f_out, *gg_out;
+    int32_t *iters, *status, *nf, *ng;
+    hipStream_t stream;
+};
+
+template <int NW, int EPT> static void launch_rci(Rci *h, const double *f, const double *g, int32_t *req)
+{
+    dim3 grid(h->batch), block(NW * 64);
+#define FL_RCI(M)                                                                                                 \
+    hipLaunchKernelGGL((rci_step_kernel<NW, EPT, M>), grid, block, 0, h->stream, h->A, h->first, h->sc, h->vec,   \
+                       h->rho, f, g, req)
+    switch (h->solver) {
+    case FL_SOLVER_SD: FL_RCI(FL_SOLVER_SD); break;
+    case FL_SOLVER_CG: FL_RCI(FL_SOLVER_CG); break;
+    case FL_SOLVER_BFGS: FL_RCI(FL_SOLVER_BFGS); break;
+    default: FL_RCI(FL_SOLVER_LBFGS); break;
+    }
+#undef FL_RCI
+}
+
+} // namespace fl
+
+extern "C" {
+
+struct fl_rci {
+    fl::Rci r;
+};
+
+int fl_rci_destroy(fl_rci *h)
+{
+    if (!h) return FL_OK;
+    void *bufs[] = {h->r.sc, h->r.vec, h->r.rho, h->r.ws, h->r.f_out, h->r.gg_out, h->r.iters, h->r.status,
+                    h->r.nf, h->r.ng};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    delete h;
+    return FL_OK;
+}
+
+int fl_rci_create(fl_rci **out, int solver, int batch, int n, const fl_options *opt, void *stream)
+{
+    if (!out || !opt || batch <= 0 || n <= 0) return FL_ERR_INVALID_ARGUMENT;
+    if (solver < FL_SOLVER_SD || solver > FL_SOLVER_BFGS) return FL_ERR_INVALID_ARGUMENT;
+    if (opt->cg_method != FL_CG_DY && opt->cg_method != FL_CG_PR) return FL_ERR_INVALID_ARGUMENT;
+    int threads = 0, ept = 0;
+    if (fl_reduction_geometry(n, &threads, &ept) != FL_OK) return FL_ERR_UNSUPPORTED_SIZE;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FL_ERR_NO_DEVICE;
+    fl_rci *h = new (std::nothrow) fl_rci();
+    if (!h) return FL_ERR_WORKSPACE;
+    std::memset(&h->r, 0, sizeof h->r);
+    fl::Rci &r = h->r;
+    r.solver = solver;
+    r.batch = batch;
+    r.n = n;
+    r.nw = threads / 64;
+    r.ept = ept;
+    r.first = 1;
+    r.stream = static_cast<hipStream_t>(stream);
+    fl::SolveArgs &A = r.A;
+    A.n = n;
+    A.batch = batch;
+    A.mem = opt->memory > 1 ? opt->memory : 1;
+    if (solver == FL_SOLVER_LBFGS && A.mem > FL_MAX_MEMORY) {
+        delete h;
+        return FL_ERR_UNSUPPORTED_SIZE;
+    }
+    A.maxit = opt->max_iteration;
+    A.strong = opt->strong != 0;
+    A.fused = opt->fused_f_fd != 0;
+    A.cg_method = opt->cg_method;
+    A.tol = opt->precision * opt->precision;
+    A.minstep = opt->min_step_length * opt->min_step_length;
+    A.c1 = opt->wolfe_c1;
+    A.c2 = opt->wolfe_c2;
+    if (opt->clamp) {
+        A.c1 = opt->wolfe_c1 > 1e-15 ? opt->wolfe_c1 : 1e-15;
+        const double lo = A.c1 + 1e-15;
+        const double c2 = opt->wolfe_c2 > lo ? opt->wolfe_c2 : lo;
+        A.c2 = c2 < 1.0 - 1e-15 ? c2 : 1.0 - 1e-15;
+    }
+    A.incr = opt->increment;
+    A.miu0 = 1.0;
+    A.precision = opt->precision;
+    const size_t npad = (size_t)threads * ept, B = (size_t)batch;
+    const size_t wsb = fl_workspace_bytes(solver, batch, n, A.mem);
+    bool ok = hipMalloc((void **)&r.sc, B * 48 * sizeof(double)) == hipSuccess &&
+              hipMalloc((void **)&r.vec, B * 3 * npad * sizeof(double)) == hipSuccess &&
+              hipMalloc((void **)&r.rho, B * FL_MAX_MEMORY * sizeof(double)) == hipSuccess &&
+              hipMalloc((void **)&r.f_out, B * sizeof(double)) == hipSuccess &&
+              hipMalloc((void **)&r.gg_out, B * sizeof(double)) == hipSuccess &&
+              hipMalloc((void **)&r.iters, B * sizeof(int32_t)) == hipSuccess &&
+              hipMalloc((void **)&r.status, B * sizeof(int32_t)) == hipSuccess &&
+              hipMalloc((void **)&r.nf, B * sizeof(int32_t)) == hipSuccess &&
+              hipMalloc((void **)&r.ng, B * sizeof(int32_t)) == hipSuccess;
+    if (ok && wsb) ok = hipMalloc((void **)&r.ws, wsb) == hipSuccess;
+    if (!ok) {
+        fl_rci_destroy(h);
+        return FL_ERR_WORKSPACE;
+    }
+    A.hist = r.ws;
+    A.f_out = r.f_out;
+    A.gg_out = r.gg_out;
+    A.iters = r.iters;
+    A.status = r.status;
+    A.nf = r.nf;
+    A.ng = r.ng;
+    *out = h;
+    return FL_OK;
+}
+
+int fl_rci_step(fl_rci *h, double *x_dev, const double *f_dev, const double *g_dev, int32_t *request_dev)
+{
+    if (!h || !x_dev || !request_dev) return FL_ERR_INVALID_ARGUMENT;
+    if (!h->r.first && (!f_dev || !g_dev)) return FL_ERR_INVALID_ARGUMENT;
+    fl::Rci *r = &h->r;
+    r->A.x = x_dev;
+    const int nw = r->nw, ept = r->ept;
+    if (nw == 1 && ept == 2) fl::launch_rci<1, 2>(r, f_dev, g_dev, request_dev);
+    else if (nw == 1 && ept == 4) fl::launch_rci<1, 4>(r, f_dev, g_dev, request_dev);
+    else if (nw == 2 && ept == 4) fl::launch_rci<2, 4>(r, f_dev, g_dev, request_dev);
+    else if (nw == 2 && ept == 8) fl::launch_rci<2, 8>(r, f_dev, g_dev, request_dev);
+    else if (nw == 4 && ept == 8) fl::launch_rci<4, 8>(r, f_dev, g_dev, request_dev);
+    else fl::launch_rci<8, 8>(r, f_dev, g_dev, request_dev);
+    r->first = 0;
+    return hipGetLastError() == hipSuccess ? FL_OK : FL_ERR_NO_DEVICE;
+}
+
+int fl_rci_results(fl_rci *h, double *f_dev, double *gg_dev, int32_t *iters_dev, int32_t *status_dev, int32_t *nf_dev,
+                   int32_t *ng_dev)
+{
+    if (!h) return FL_ERR_INVALID_ARGUMENT;
+    const size_t B = (size_t)h->r.batch;
+    hipStream_t st = h->r.stream;
+    bool ok = true;
+    if (f_dev) ok &= hipMemcpyAsync(f_dev, h->r.f_out, B * 8, hipMemcpyDeviceToDevice, st) == hipSuccess;
+    if (gg_dev) ok &= hipMemcpyAsync(gg_dev, h->r.gg_out, B * 8, hipMemcpyDeviceToDevice, st) == hipSuccess;
+    if (iters_dev) ok &= hipMemcpyAsync(iters_dev, h->r.iters, B * 4, hipMemcpyDeviceToDevice, st) == hipSuccess;
+    if (status_dev) ok &= hipMemcpyAsync(status_dev, h->r.status, B * 4, hipMemcpyDeviceToDevice, st) == hipSuccess;
+    if (nf_dev) ok &= hipMemcpyAsync(nf_dev, h->r.nf, B * 4, hipMemcpyDeviceToDevice, st) == hipSuccess;
+    if (ng_dev) ok &= hipMemcpyAsync(ng_dev, h->r.ng, B * 4, hipMemcpyDeviceToDevice, st) == hipSuccess;
+    return ok ? FL_OK : FL_ERR_NO_DEVICE;
+}
+
+// ------------------------------------------------------------------ legacy entry points
+typedef void (*f_cb)(double &, const double *, const int &);
+typedef void (*fd_cb)(double *, const double *, const int &);
+typedef int (*ffd_cb)(double &, double *, const double *, const int &);
+typedef int (*fdd_cb)(double *, const double *, const int &);
+
+// One problem, host callbacks: the machine steps on the GPU, f / f' are evaluated by the caller's
+// code on the host exactly when the reference would call them (request bits).  Returns the status.
+static int legacy_solve(int solver, const char *name, f_cb f, fd_cb fd, ffd_cb f_fd, double *x, int n,
+                        const fl_options &o, int warn)
+{
+    fl_rci *h = nullptr;
+    int rc = fl_rci_create(&h, solver, 1, n, &o, nullptr);
+    if (rc != FL_OK) {
+        std::fprintf(stderr, "FortranLibrary(MI355X) %s: cannot run on the device (error %d); x is unchanged\n", name, rc);
+        return rc;
+    }
+    double *xd = nullptr, *fdv = nullptr, *gd = nullptr;
+    int32_t *rqd = nullptr;
+    std::vector<double> g(n);
+    double fx = 0.0;
+    int32_t rq = 0, status = FL_STATUS_MAXIT;
+    bool ok = hipMalloc((void **)&xd, sizeof(double) * n) == hipSuccess &&
+              hipMalloc((void **)&fdv, sizeof(double)) == hipSuccess &&
+              hipMalloc((void **)&gd, sizeof(double) * n) == hipSuccess &&
+              hipMalloc((void **)&rqd, sizeof(int32_t)) == hipSuccess;
+    ok = ok && hipMemcpy(xd, x, sizeof(double) * n, hipMemcpyHostToDevice) == hipSuccess;
+    while (ok) {
+        if (fl_rci_step(h, xd, fdv, gd, rqd) != FL_OK) { ok = false; break; }
+        if (hipMemcpy(&rq, rqd, sizeof rq, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+        if (rq == 0) break;
+        if (!(rq & FL_REQ_SAME))
+            if (hipMemcpy(x, xd, sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+        const bool wf = rq & FL_REQ_F, wg = rq & FL_REQ_G;
+        if (wf && wg && f_fd) {
+            (void)f_fd(fx, g.data(), x, n); // integer return value is ignored like the reference does (NO.f90:437)
+        } else {
+            if (wf) f(fx, x, n);
+            if (wg) fd(g.data(), x, n);
+        }
+        if (wf) ok = ok && hipMemcpy(fdv, &fx, sizeof fx, hipMemcpyHostToDevice) == hipSuccess;
+        if (wg) ok = ok && hipMemcpy(gd, g.data(), sizeof(double) * n, hipMemcpyHostToDevice) == hipSuccess;
+    }
+    double gg = 0.0;
+    if (ok) {
+        ok = hipMemcpy(x, xd, sizeof(double) * n, hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(&status, h->r.status, sizeof status, hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(&gg, h->r.gg_out, sizeof gg, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    if (!ok) std::fprintf(stderr, "FortranLibrary(MI355X) %s: HIP error during the solve\n", name);
+    if (ok && warn) { // the reference's warnings (e.g. NO.f90:580-583, 616-619)
+        if (status == FL_STATUS_MAXIT) {
+            std::printf(" Failed %s: max iteration exceeded!\n Euclidean norm of gradient = %24.16E\n", name, sqrt(gg));
+        } else if (status == FL_STATUS_STEP_CONVERGED) {
+            std::printf(" %s warning: step length has converged, but gradient norm has not met accuracy goal\n"
+                        " Euclidean norm of gradient = %24.16E\n", name, sqrt(gg));
+        }
+    }
+    if (xd) (void)hipFree(xd);
+    if (fdv) (void)hipFree(fdv);
+    if (gd) (void)hipFree(gd);
+    if (rqd) (void)hipFree(rqd);
+    fl_rci_destroy(h);
+    return ok ? status : FL_ERR_NO_DEVICE;
+}
+
+// optional dummy arguments arrive as NULL when absent (Fortran callers); C++ always passes all
+static void legacy_options(fl_options &o, int solver, const int32_t *Strong, const int *MaxIteration,
+                           const double *Precision, const double *MinStepLength, const double *WolfeConst1,
+                           const double *WolfeConst2, const double *Increment, ffd_cb f_fd)
+{
+    fl_default_options(&o, solver);
+    if (Strong) o.strong = *Strong != 0;
+    if (MaxIteration) o.max_iteration = *MaxIteration;
+    if (Precision) o.precision = *Precision;
+    if (MinStepLength) o.min_step_length = *MinStepLength;
+    if (WolfeConst1) o.wolfe_c1 = *WolfeConst1;
+    if (WolfeConst2) o.wolfe_c2 = *WolfeConst2;
+    if (Increment) o.increment = *Increment;
+    o.fused_f_fd = f_fd != nullptr;
+}
+static int warn_of(const int32_t *Warning) { return Warning ? *Warning != 0 : 1; }
+
+static int cg_method_of(const char *Method, int len)
+{
+    if (!Method) return FL_CG_DY; // Method absent: 'DY' (NO.f90:214-215)
+    // character*2::type = Method: the first two characters decide (NO.f90:207, 214)
+    char t[2] = {len > 0 ? Method[0] : ' ', len > 1 ? Method[1] : ' '};
+    if (t[0] == 'D' && t[1] == 'Y') return FL_CG_DY;
+    if (t[0] == 'P' && t[1] == 'R') return FL_CG_PR;
+    return -1;
+}
+
+#define FL_LEGACY_COMMON                                                                                          \
+    const int32_t *Strong, const int32_t *Warning, const int *MaxIteration, const double *Precision,              \
+        const double *MinStepLength, const double *WolfeConst1, const double *WolfeConst2, const double *Increment
+
+// subroutine SteepestDescent(f,fd,x,dim,f_fd,Strong,...)  NO.f90:55 ; hpp:279-292
+void __nonlinearoptimization_MOD_steepestdescent(f_cb f, fd_cb fd, double *x, const int *dim, ffd_cb f_fd,
+                                                 FL_LEGACY_COMMON)
+{
+    fl_options o;
+    legacy_options(o, FL_SOLVER_SD, Strong, MaxIteration, Precision, MinStepLength, WolfeConst1, WolfeConst2,
+                   Increment, f_fd);
+    legacy_solve(FL_SOLVER_SD, "steepest descent", f, fd, f_fd, x, *dim, o, warn_of(Warning));
+}
+
+// subroutine ConjugateGradient(f,fd,x,dim,Method,f_fd,Strong,...)  NO.f90:193 ; hpp:309-324
+void __nonlinearoptimization_MOD_conjugategradient(f_cb f, fd_cb fd, double *x, const int *dim, const char *Method,
+                                                   ffd_cb f_fd, FL_LEGACY_COMMON, int len_Method)
+{
+    fl_options o;
+    legacy_options(o, FL_SOLVER_CG, Strong, MaxIteration, Precision, MinStepLength, WolfeConst1, WolfeConst2,
+                   Increment, f_fd);
+    const int m = cg_method_of(Method, len_Method);
+    if (m < 0) { // reference: write + stop (NO.f90:345); a library must not kill its caller: report and return
+        std::printf(" Program abort: unsupported conjugate gradient method %.*s\n", len_Method, Method);
+        return;
+    }
+    o.cg_method = m;
+    legacy_solve(FL_SOLVER_CG, "conjugate gradient", f, fd, f_fd, x, *dim, o, warn_of(Warning));
+}
+
+// subroutine ConjugateGradient_basic(...)  NO.f90:2249-2346 ; hpp:294-307: every argument required,
+// no f_fd, and NO fail-safe clamps on the Wolfe constants
+void __nonlinearoptimization_MOD_conjugategradient_basic(f_cb f, fd_cb fd, double *x, const int *dim,
+                                                         const char *Method, FL_LEGACY_COMMON, int len_Method)
+{
+    fl_options o;
+    legacy_options(o, FL_SOLVER_CG, Strong, MaxIteration, Precision, MinStepLength, WolfeConst1, WolfeConst2,
+                   Increment, nullptr);
+    o.clamp = 0;
+    const int m = cg_method_of(Method, len_Method);
+    if (m < 0) {
+        std::printf(" Program abort: unsupported conjugate gradient method %.*s\n", len_Method, Method);
+        return;
+    }
+    o.cg_method = m;
+    legacy_solve(FL_SOLVER_CG, "conjugate gradient", f, fd, nullptr, x, *dim, o, warn_of(Warning));
+}
+
+// subroutine LBFGS(f,fd,x,dim,Memory,f_fd,Strong,...)  NO.f90:398 (no C++ wrapper in the reference header)
+void __nonlinearoptimization_MOD_lbfgs(f_cb f, fd_cb fd, double *x, const int *dim, const int *Memory, ffd_cb f_fd,
+                                       FL_LEGACY_COMMON)
+{
+    fl_options o;
+    legacy_options(o, FL_SOLVER_LBFGS, Strong, MaxIteration, Precision, MinStepLength, WolfeConst1, WolfeConst2,
+                   Increment, f_fd);
+    if (Memory) o.memory = *Memory;
+    legacy_solve(FL_SOLVER_LBFGS, "L-BFGS", f, fd, f_fd, x, *dim, o, warn_of(Warning));
+}
+
+// subroutine BFGS(f,fd,x,dim,fdd,ExactStep,f_fd,Strong,...)  NO.f90:632 ; hpp:326-342.
+// The device path is the reference's ExactStep<=0 branch (rank-2 updates only).  ExactStep>0 asks
+// for an exact inverse Hessian every ExactStep iterations (fdd or MKL djacobi + dpotri, NO.f90:674-682,
+// 949-956): not on the device yet -- said once on stdout when Warning is on, then solved without.
+void __nonlinearoptimization_MOD_bfgs(f_cb f, fd_cb fd, double *x, const int *dim, fdd_cb fdd, const int *ExactStep,
+                                      ffd_cb f_fd, FL_LEGACY_COMMON)
+{
+    (void)fdd;
+    fl_options o;
+    legacy_options(o, FL_SOLVER_BFGS, Strong, MaxIteration, Precision, MinStepLength, WolfeConst1, WolfeConst2,
+                   Increment, f_fd);
+    const int freq = ExactStep ? *ExactStep : 20;
+    if (freq > 0 && warn_of(Warning))
+        std::printf(" BFGS (MI355X): exact Hessian refresh (ExactStep=%d) is not available on the device path;"
+                    " continuing with quasi-Newton updates only (ExactStep=0)\n", freq);
+    legacy_solve(FL_SOLVER_BFGS, "BFGS", f, fd, f_fd, x, *dim, o, warn_of(Warning));
+}
+
+// ifort manglings of the same procedures (cpp/NonlinearOptimization.hpp:11-123)
+void nonlinearoptimization_mp_steepestdescent_(f_cb f, fd_cb fd, double *x, const int *dim, ffd_cb f_fd,
+                                               FL_LEGACY_COMMON)
+{
+    __nonlinearoptimization_MOD_steepestdescent(f, fd, x, dim, f_fd, Strong, Warning, MaxIteration, Precision,
+                                                MinStepLength, WolfeConst1, WolfeConst2, Increment);
+}
+void nonlinearoptimization_mp_conjugategradient_(f_cb f, fd_cb fd, double *x, const int *dim, const char *Method,
+                                                 ffd_cb f_fd, FL_LEGACY_COMMON, int len_Method)
+{
+    __nonlinearoptimization_MOD_conjugategradient(f, fd, x, dim, Method, f_fd, Strong, Warning, MaxIteration,
+                                                  Precision, MinStepLength, WolfeConst1, WolfeConst2, Increment,
+                                                  len_Method);
+}
+void nonlinearoptimization_mp_conjugategradient_basic_(f_cb f, fd_cb fd, double *x, const int *dim,
+                                                       const char *Method, FL_LEGACY_COMMON, int len_Method)
+{
+    __nonlinearoptimization_MOD_conjugategradient_basic(f, fd, x, dim, Method, Strong, Warning, MaxIteration,
+                                                        Precision, MinStepLength, WolfeConst1, WolfeConst2,
+                                                        Increment, len_Method);
+}
+void nonlinearoptimization_mp_lbfgs_(f_cb f, fd_cb fd, double *x, const int *dim, const int *Memory, ffd_cb f_fd,
+                                     FL_LEGACY_COMMON)
+{
+    __nonlinearoptimization_MOD_lbfgs(f, fd, x, dim, Memory, f_fd, Strong, Warning, MaxIteration, Precision,
+                                      MinStepLength, WolfeConst1, WolfeConst2, Increment);
+}
+void nonlinearoptimization_mp_bfgs_(f_cb f, fd_cb fd, double *x, const int *dim, fdd_cb fdd, const int *ExactStep,
+                                    ffd_cb f_fd, FL_LEGACY_COMMON)
+{
+    __nonlinearoptimization_MOD_bfgs(f, fd, x, dim, fdd, ExactStep, f_fd, Strong, Warning, MaxIteration, Precision,
+                                     MinStepLength, WolfeConst1, WolfeConst2, Increment);
+}
+
+} // extern "C"

@@ -1,0 +1,65 @@
+/*
+ * fl_legacy.h -- the reference's own single-problem entry points, exported by libFL.so (MI355X)
+ * under the mangled names the reference's C++ header binds, so existing callers of
+ * `#include <FortranLibrary.hpp>` / `FL::NO::*` keep linking against -lFL unchanged.
+ *
+ * Replaces (file:line in /root/reference):
+ *   __nonlinearoptimization_MOD_steepestdescent          cpp/NonlinearOptimization.hpp:279-292   (NO.f90:55)
+ *   __nonlinearoptimization_MOD_conjugategradient_basic  cpp/NonlinearOptimization.hpp:294-307   (NO.f90:2249)
+ *   __nonlinearoptimization_MOD_conjugategradient        cpp/NonlinearOptimization.hpp:309-324   (NO.f90:193)
+ *   __nonlinearoptimization_MOD_bfgs                     cpp/NonlinearOptimization.hpp:326-342   (NO.f90:632)
+ *   __nonlinearoptimization_MOD_lbfgs                    (Fortran only in the reference)          (NO.f90:398)
+ *   nonlinearoptimization_mp_*_                          the ifort manglings, hpp:11-123
+ * Conventions are the reference's (cpp/README.md:11-18): every argument by reference, an absent
+ * Fortran optional = NULL, logical = 4-byte integer (nonzero = true), character(*) = pointer plus a
+ * hidden length appended by value.  Callbacks run on the HOST, exactly when the reference would call
+ * them; all solver arithmetic runs on the GPU (reverse communication, fl_nlopt.h: fl_rci_*).
+ * x is the only result (in/out), warnings go to stdout when Warning is true, like the reference.
+ * Differences: an unknown Method prints the reference's message and returns instead of `stop`;
+ * BFGS runs the ExactStep<=0 branch (ExactStep>0 is announced and ignored: not on the device yet).
+ * NewtonRaphson / TrustRegion / AugmentedLagrangian legacy symbols are not exported.
+ */
+#ifndef FL_LEGACY_H
+#define FL_LEGACY_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void (*fl_f_cb)(double *fx, const double *x, const int *dim);             /* subroutine f(f(x),x,dim)  */
+typedef void (*fl_fd_cb)(double *fdx, const double *x, const int *dim);           /* subroutine fd(f'(x),x,dim) */
+typedef int (*fl_f_fd_cb)(double *fx, double *fdx, const double *x, const int *dim); /* integer function f_fd   */
+typedef int (*fl_fdd_cb)(double *fddx, const double *x, const int *dim);          /* integer function fdd     */
+
+#define FL_LEGACY_COMMON_ARGS                                                                                   \
+    const int32_t *Strong, const int32_t *Warning, const int *MaxIteration, const double *Precision,            \
+        const double *MinStepLength, const double *WolfeConst1, const double *WolfeConst2, const double *Increment
+
+void __nonlinearoptimization_MOD_steepestdescent(fl_f_cb f, fl_fd_cb fd, double *x, const int *dim, fl_f_fd_cb f_fd,
+                                                 FL_LEGACY_COMMON_ARGS);
+void __nonlinearoptimization_MOD_conjugategradient_basic(fl_f_cb f, fl_fd_cb fd, double *x, const int *dim,
+                                                         const char *Method, FL_LEGACY_COMMON_ARGS, int len_Method);
+void __nonlinearoptimization_MOD_conjugategradient(fl_f_cb f, fl_fd_cb fd, double *x, const int *dim,
+                                                   const char *Method, fl_f_fd_cb f_fd, FL_LEGACY_COMMON_ARGS,
+                                                   int len_Method);
+void __nonlinearoptimization_MOD_lbfgs(fl_f_cb f, fl_fd_cb fd, double *x, const int *dim, const int *Memory,
+                                       fl_f_fd_cb f_fd, FL_LEGACY_COMMON_ARGS);
+void __nonlinearoptimization_MOD_bfgs(fl_f_cb f, fl_fd_cb fd, double *x, const int *dim, fl_fdd_cb fdd,
+                                      const int *ExactStep, fl_f_fd_cb f_fd, FL_LEGACY_COMMON_ARGS);
+
+void nonlinearoptimization_mp_steepestdescent_(fl_f_cb f, fl_fd_cb fd, double *x, const int *dim, fl_f_fd_cb f_fd,
+                                               FL_LEGACY_COMMON_ARGS);
+void nonlinearoptimization_mp_conjugategradient_basic_(fl_f_cb f, fl_fd_cb fd, double *x, const int *dim,
+                                                       const char *Method, FL_LEGACY_COMMON_ARGS, int len_Method);
+void nonlinearoptimization_mp_conjugategradient_(fl_f_cb f, fl_fd_cb fd, double *x, const int *dim,
+                                                 const char *Method, fl_f_fd_cb f_fd, FL_LEGACY_COMMON_ARGS,
+                                                 int len_Method);
+void nonlinearoptimization_mp_lbfgs_(fl_f_cb f, fl_fd_cb fd, double *x, const int *dim, const int *Memory,
+                                     fl_f_fd_cb f_fd, FL_LEGACY_COMMON_ARGS);
+void nonlinearoptimization_mp_bfgs_(fl_f_cb f, fl_fd_cb fd, double *x, const int *dim, fl_fdd_cb fdd,
+                                    const int *ExactStep, fl_f_fd_cb f_fd, FL_LEGACY_COMMON_ARGS);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

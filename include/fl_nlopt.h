@@ -147,6 +147,30 @@ int fl_augmented_lagrangian_batched(int solver, int objective, int batch, int n,
                                     double *cnorm2_dev, int32_t *iters_dev, int32_t *outer_dev, int32_t *status_dev,
                                     int32_t *nf_dev, int32_t *ng_dev, void *stream);
 
+/* ---- reverse communication: objectives evaluated by the caller -------------------------------
+ * The reference calls back into user code for every evaluation (subroutine f(fx,x,dim), fd(g,x,dim),
+ * integer function f_fd(fx,g,x,dim): NO.f90:33-38).  For a batch on the GPU the same protocol is an
+ * "ask / tell" loop: the solver machines live in device memory; every fl_rci_step
+ *     1. takes the caller's evaluations f_dev[batch], g_dev[batch][n] at the points it asked for,
+ *     2. advances every problem to its next request,
+ *     3. overwrites x_dev[batch][n] with the next points and sets request_dev[batch]:
+ *        bit 0 (1) evaluate f, bit 1 (2) evaluate grad f, bit 2 (4) the point is unchanged since the
+ *        previous request (only the newly requested quantity is read), 0 = this problem has finished
+ *        (x_dev holds its minimiser and is no longer touched).
+ * The bits are exactly the reference's callback pattern (f only while Armijo fails, f' only once it
+ * holds, f_fd when both are set and opt->fused_f_fd is on), so wrapping host callbacks reproduces the
+ * reference's evaluation counts.  First call: x_dev = initial guesses, f_dev/g_dev may be NULL.
+ * Arrays whose bit was not requested are not read.  solver: FL_SOLVER_SD | CG | LBFGS | BFGS
+ * (BFGS: ExactStep <= 0 path).  The handle owns its device buffers (history ring / inverse Hessians,
+ * parked machine state). */
+typedef struct fl_rci fl_rci;
+int fl_rci_create(fl_rci **handle, int solver, int batch, int n, const fl_options *opt, void *stream);
+int fl_rci_step(fl_rci *handle, double *x_dev, const double *f_dev, const double *g_dev, int32_t *request_dev);
+/* copies the per-problem outputs (device pointers, each may be NULL) after all requests are 0 */
+int fl_rci_results(fl_rci *handle, double *f_dev, double *gg_dev, int32_t *iters_dev, int32_t *status_dev,
+                   int32_t *nf_dev, int32_t *ng_dev);
+int fl_rci_destroy(fl_rci *handle);
+
 /* The L-BFGS two-loop recursion alone (Before(), NO.f90:586-608) for a batch:
  * p = -H_k g from a full ring of `memory` pairs.  hist_dev is the solver's
  * history layout [batch][2*memory][npad] (npad = threads*ept; pair i: s at

@@ -30,6 +30,8 @@ void flo_set_sum_mode(int mode, int threads, int ept)
     g_ept = ept;
 }
 
+int flo_get_sum_mode(void) { return g_mode; }
+
 /* element held by thread t in register slot k: 16-byte (2-double) chunks are
  * dealt round-robin over the threads -- the HIP kernels' coalesced layout */
 static inline int elem_of(int t, int k, int T) { return (((k >> 1) * T + t) << 1) + (k & 1); }

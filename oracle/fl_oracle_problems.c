@@ -20,7 +20,8 @@
 #endif
 
 extern double flo_tree_sum(int n, const double *term);
-static __thread int p_mode = FLO_SUM_SEQ;
+extern int flo_get_sum_mode(void);
+#define p_mode (flo_get_sum_mode())
 
 static double sum_terms(int n, const double *t)
 {
@@ -137,11 +138,7 @@ void flo_prob_cd(double *cdx, const double *x, int m, int n, void *ctx)
         for (int i = j * w; i < (j + 1) * w; ++i) cdx[(size_t)j * n + i] = 2.0 * x[i];
 }
 
-static void set_modes(int sum_mode, int threads, int ept)
-{
-    flo_set_sum_mode(sum_mode, threads, ept);
-    p_mode = sum_mode;
-}
+static void set_modes(int sum_mode, int threads, int ept) { flo_set_sum_mode(sum_mode, threads, ept); }
 
 int flo_solve_batch(int solver, int kind, int B, int n, double *x, const double *d, const double *b,
                     const flo_opts *o, int use_ffd, int bfgs_form, int sum_mode, int threads, int ept,

@@ -28,6 +28,12 @@ def test_c_abi_library_exports_every_declared_symbol():
     for nme in names:
         assert hasattr(lib, nme), nme
     assert lib.fl_version() >= 100
+    # the reference's own mangled entry points (include/fl_legacy.h; cpp/NonlinearOptimization.hpp:278-393)
+    leg = open(os.path.join(ROOT, "include", "fl_legacy.h")).read()
+    lnames = sorted(set(re.findall(r"\b(__nonlinearoptimization_MOD_[a-z_]+|nonlinearoptimization_mp_[a-z_]+_)\s*\(", leg)))
+    assert len(lnames) == 10
+    for nme in lnames:
+        assert hasattr(lib, nme), nme
     t, e = C.c_int(), C.c_int()
     for n, (T, E) in {10: (64, 2), 256: (64, 4), 512: (128, 4), 1024: (128, 8), 2048: (256, 8), 4096: (512, 8)}.items():
         assert lib.fl_reduction_geometry(n, C.byref(t), C.byref(e)) == 0 and (t.value, e.value) == (T, E)
