@@ -153,11 +153,11 @@ def test_rci_batched_torch_objective_equals_fused_kernel():
 
     for solver in (NLO.LBFGS_, NLO.CG, NLO.BFGS_):
         x = torch.zeros(B, n, dtype=torch.float64, device=dev)
-        out = NLO.minimize_rci(solver, x, fun, Precision=1e-7)
+        out = NLO.minimize_rci(solver, x, fun, Precision=1e-6)
         assert np.all(out["status"].cpu().numpy() == O.CONVERGED)
         xs = b / d
-        assert float(((x - xs).norm(dim=1) / xs.norm(dim=1)).max()) < 1e-6
+        assert float(((x - xs).norm(dim=1) / xs.norm(dim=1)).max()) < 1e-5
         x2 = torch.zeros(B, n, dtype=torch.float64, device=dev)
         fused = {NLO.LBFGS_: NLO.LBFGS, NLO.CG: NLO.ConjugateGradient, NLO.BFGS_: NLO.BFGS}[solver]
-        ref = fused(NLO.DIAGQUAD, x2, d, b, Precision=1e-7)
+        ref = fused(NLO.DIAGQUAD, x2, d, b, Precision=1e-6)
         assert torch.allclose(out["f"], ref["f"], rtol=1e-10, atol=0)
