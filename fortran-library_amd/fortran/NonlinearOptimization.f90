@@ -1,0 +1,236 @@
+!Nonlinear optimization routines -- MI355X build of the line-search optimisers
+!
+!Drop-in replacement for the line-search part of the reference module
+!(/root/reference/source/NonlinearOptimization.f90): same module name, same procedure
+!names, same dummy-argument names (keyword calls keep working), same optional-ness,
+!same callback conventions:
+!    subroutine f(f(x), x, dim)
+!    subroutine fd(f'(x), x, dim)
+!    integer function f_fd(f(x), f'(x), x, dim)
+!This file contains interfaces and argument marshalling only: every procedure forwards
+!through iso_c_binding to libFL.so (include/fl_legacy.h, include/fl_nlopt.h), where the
+!solver runs on the GPU and calls f / fd / f_fd back on the host when it needs them.
+!  SteepestDescent   <- reference NonlinearOptimization.f90:55
+!  ConjugateGradient <- reference NonlinearOptimization.f90:193 (Method = 'DY' | 'PR')
+!  LBFGS             <- reference NonlinearOptimization.f90:398
+!  BFGS              <- reference NonlinearOptimization.f90:632 (ExactStep <= 0 branch on the device)
+!New: LBFGS_batched / ConjugateGradient_batched -- batches of independent problems with
+!device-resident data and built-in objectives (include/fl_nlopt.h).
+!Not provided (out of scope, SURVEY.md section 8f): NewtonRaphson, TrustRegion (MKL RCI),
+!LagrangianMultiplier; AugmentedLagrangian is available in batched form from C / Python.
+module NonlinearOptimization
+    use iso_c_binding
+    implicit none
+
+    integer(c_int),parameter::FL_OBJ_QUARTIC=0,FL_OBJ_ROSENBROCK=1,FL_OBJ_DIAGQUAD=2
+    integer(c_int),parameter::FL_SOLVER_SD=0,FL_SOLVER_CG=1,FL_SOLVER_LBFGS=2,FL_SOLVER_BFGS=3
+
+    type,bind(C)::fl_options!include/fl_nlopt.h: struct fl_options
+        integer(c_int32_t)::strong,max_iteration
+        real(c_double)::precision,min_step_length,wolfe_c1,wolfe_c2,increment
+        integer(c_int32_t)::memory,cg_method,fused_f_fd,clamp
+    end type fl_options
+
+    interface
+        subroutine flc_steepestdescent(f,fd,x,dim,f_fd,Strong,Warning,MaxIteration,Precision,MinStepLength,&
+        WolfeConst1,WolfeConst2,Increment) bind(C,name='__nonlinearoptimization_MOD_steepestdescent')
+            import
+            type(c_funptr),value::f,fd,f_fd
+            real(c_double)::x(*)
+            integer(c_int),intent(in)::dim
+            type(c_ptr),value::Strong,Warning,MaxIteration,Precision,MinStepLength,WolfeConst1,WolfeConst2,Increment
+        end subroutine flc_steepestdescent
+        subroutine flc_conjugategradient(f,fd,x,dim,Method,f_fd,Strong,Warning,MaxIteration,Precision,MinStepLength,&
+        WolfeConst1,WolfeConst2,Increment,len_Method) bind(C,name='__nonlinearoptimization_MOD_conjugategradient')
+            import
+            type(c_funptr),value::f,fd,f_fd
+            real(c_double)::x(*)
+            integer(c_int),intent(in)::dim
+            character(kind=c_char)::Method(*)
+            type(c_ptr),value::Strong,Warning,MaxIteration,Precision,MinStepLength,WolfeConst1,WolfeConst2,Increment
+            integer(c_int),value::len_Method
+        end subroutine flc_conjugategradient
+        subroutine flc_lbfgs(f,fd,x,dim,Memory,f_fd,Strong,Warning,MaxIteration,Precision,MinStepLength,&
+        WolfeConst1,WolfeConst2,Increment) bind(C,name='__nonlinearoptimization_MOD_lbfgs')
+            import
+            type(c_funptr),value::f,fd,f_fd
+            real(c_double)::x(*)
+            integer(c_int),intent(in)::dim
+            type(c_ptr),value::Memory,Strong,Warning,MaxIteration,Precision,MinStepLength,WolfeConst1,WolfeConst2,Increment
+        end subroutine flc_lbfgs
+        subroutine flc_bfgs(f,fd,x,dim,fdd,ExactStep,f_fd,Strong,Warning,MaxIteration,Precision,MinStepLength,&
+        WolfeConst1,WolfeConst2,Increment) bind(C,name='__nonlinearoptimization_MOD_bfgs')
+            import
+            type(c_funptr),value::f,fd,fdd,f_fd
+            real(c_double)::x(*)
+            integer(c_int),intent(in)::dim
+            type(c_ptr),value::ExactStep,Strong,Warning,MaxIteration,Precision,MinStepLength,WolfeConst1,WolfeConst2,Increment
+        end subroutine flc_bfgs
+        subroutine fl_default_options(opt,solver) bind(C,name='fl_default_options')
+            import
+            type(fl_options),intent(out)::opt
+            integer(c_int),value::solver
+        end subroutine fl_default_options
+        integer(c_size_t) function fl_workspace_bytes(solver,batch,n,memory) bind(C,name='fl_workspace_bytes')
+            import
+            integer(c_int),value::solver,batch,n,memory
+        end function fl_workspace_bytes
+        integer(c_int) function fl_lbfgs_batched(objective,batch,n,x,d,b,opt,ws,ws_bytes,f,gg,iters,status,nf,ng,stream)&
+        bind(C,name='fl_lbfgs_batched')
+            import
+            integer(c_int),value::objective,batch,n
+            type(c_ptr),value::x,d,b,ws,f,gg,iters,status,nf,ng,stream!device pointers
+            type(fl_options),intent(in)::opt
+            integer(c_size_t),value::ws_bytes
+        end function fl_lbfgs_batched
+        integer(c_int) function fl_conjugate_gradient_batched(objective,batch,n,x,d,b,opt,f,gg,iters,status,nf,ng,stream)&
+        bind(C,name='fl_conjugate_gradient_batched')
+            import
+            integer(c_int),value::objective,batch,n
+            type(c_ptr),value::x,d,b,f,gg,iters,status,nf,ng,stream
+            type(fl_options),intent(in)::opt
+        end function fl_conjugate_gradient_batched
+    end interface
+
+contains
+!-------------- Line search --------------
+    !Optional arguments travel as C pointers: the address of a local copy when present, NULL when absent
+    !(the convention of the reference's C++ header, cpp/README.md:11-18); logical -> 4-byte integer
+
+    subroutine SteepestDescent(f, fd, x, dim, &
+    f_fd, Strong, Warning, MaxIteration, Precision, MinStepLength, WolfeConst1, WolfeConst2, Increment)
+        external::f,fd
+        integer,intent(in)::dim
+        real*8,dimension(dim),intent(inout)::x
+        integer,external,optional::f_fd
+        logical,intent(in),optional::Strong,Warning
+        integer,intent(in),optional::MaxIteration
+        real*8,intent(in),optional::Precision,MinStepLength,WolfeConst1,WolfeConst2,Increment
+        integer(c_int32_t),target::ls(2)
+        integer(c_int),target::li(1)
+        real(c_double),target::lr(5)
+        type(c_ptr)::p(8)
+        type(c_funptr)::pf_fd
+        call pack_common(p,ls,li,lr,Strong,Warning,MaxIteration,Precision,MinStepLength,WolfeConst1,WolfeConst2,Increment)
+        pf_fd=c_null_funptr; if(present(f_fd)) pf_fd=c_funloc(f_fd)
+        call flc_steepestdescent(c_funloc(f),c_funloc(fd),x,dim,pf_fd,p(1),p(2),p(3),p(4),p(5),p(6),p(7),p(8))
+    end subroutine SteepestDescent
+
+    subroutine ConjugateGradient(f, fd, x, dim, &
+    Method, &
+    f_fd, Strong, Warning, MaxIteration, Precision, MinStepLength, WolfeConst1, WolfeConst2, Increment)
+        external::f,fd
+        integer,intent(in)::dim
+        real*8,dimension(dim),intent(inout)::x
+        character(*),intent(in),optional::Method
+        integer,external,optional::f_fd
+        logical,intent(in),optional::Strong,Warning
+        integer,intent(in),optional::MaxIteration
+        real*8,intent(in),optional::Precision,MinStepLength,WolfeConst1,WolfeConst2,Increment
+        integer(c_int32_t),target::ls(2)
+        integer(c_int),target::li(1)
+        real(c_double),target::lr(5)
+        type(c_ptr)::p(8)
+        type(c_funptr)::pf_fd
+        character(kind=c_char)::m(2)
+        m(1)='D'; m(2)='Y'!default = DY (reference NonlinearOptimization.f90:214-215)
+        if(present(Method)) then
+            m=' '
+            if(len(Method)>=1) m(1)=Method(1:1)
+            if(len(Method)>=2) m(2)=Method(2:2)
+        end if
+        call pack_common(p,ls,li,lr,Strong,Warning,MaxIteration,Precision,MinStepLength,WolfeConst1,WolfeConst2,Increment)
+        pf_fd=c_null_funptr; if(present(f_fd)) pf_fd=c_funloc(f_fd)
+        call flc_conjugategradient(c_funloc(f),c_funloc(fd),x,dim,m,pf_fd,p(1),p(2),p(3),p(4),p(5),p(6),p(7),p(8),2_c_int)
+    end subroutine ConjugateGradient
+
+    subroutine LBFGS(f, fd, x, dim, &
+    Memory, &
+    f_fd, Strong, Warning, MaxIteration, Precision, MinStepLength, WolfeConst1, WolfeConst2, Increment)
+        external::f,fd
+        integer,intent(in)::dim
+        real*8,dimension(dim),intent(inout)::x
+        integer,external,optional::f_fd
+        logical,intent(in),optional::Strong,Warning
+        integer,intent(in),optional::Memory,MaxIteration
+        real*8,intent(in),optional::Precision,MinStepLength,WolfeConst1,WolfeConst2,Increment
+        integer(c_int32_t),target::ls(2)
+        integer(c_int),target::li(1),lm
+        real(c_double),target::lr(5)
+        type(c_ptr)::p(8),pm
+        type(c_funptr)::pf_fd
+        call pack_common(p,ls,li,lr,Strong,Warning,MaxIteration,Precision,MinStepLength,WolfeConst1,WolfeConst2,Increment)
+        pm=c_null_ptr
+        if(present(Memory)) then; lm=Memory; pm=c_loc(lm); end if
+        pf_fd=c_null_funptr; if(present(f_fd)) pf_fd=c_funloc(f_fd)
+        call flc_lbfgs(c_funloc(f),c_funloc(fd),x,dim,pm,pf_fd,p(1),p(2),p(3),p(4),p(5),p(6),p(7),p(8))
+    end subroutine LBFGS
+
+    subroutine BFGS(f, fd, x, dim, &
+    fdd, ExactStep, &
+    f_fd, Strong, Warning, MaxIteration, Precision, MinStepLength, WolfeConst1, WolfeConst2, Increment)
+        external::f,fd
+        integer,intent(in)::dim
+        real*8,dimension(dim),intent(inout)::x
+        integer,external,optional::fdd,f_fd
+        logical,intent(in),optional::Strong,Warning
+        integer,intent(in),optional::ExactStep,MaxIteration
+        real*8,intent(in),optional::Precision,MinStepLength,WolfeConst1,WolfeConst2,Increment
+        integer(c_int32_t),target::ls(2)
+        integer(c_int),target::li(1),le
+        real(c_double),target::lr(5)
+        type(c_ptr)::p(8),pe
+        type(c_funptr)::pf_fd,pfdd
+        call pack_common(p,ls,li,lr,Strong,Warning,MaxIteration,Precision,MinStepLength,WolfeConst1,WolfeConst2,Increment)
+        pe=c_null_ptr
+        if(present(ExactStep)) then; le=ExactStep; pe=c_loc(le); end if
+        pf_fd=c_null_funptr; if(present(f_fd)) pf_fd=c_funloc(f_fd)
+        pfdd=c_null_funptr; if(present(fdd)) pfdd=c_funloc(fdd)
+        call flc_bfgs(c_funloc(f),c_funloc(fd),x,dim,pfdd,pe,pf_fd,p(1),p(2),p(3),p(4),p(5),p(6),p(7),p(8))
+    end subroutine BFGS
+
+    subroutine pack_common(p,ls,li,lr,Strong,Warning,MaxIteration,Precision,MinStepLength,WolfeConst1,WolfeConst2,Increment)
+        type(c_ptr),intent(out)::p(8)
+        integer(c_int32_t),target,intent(out)::ls(2)
+        integer(c_int),target,intent(out)::li(1)
+        real(c_double),target,intent(out)::lr(5)
+        logical,intent(in),optional::Strong,Warning
+        integer,intent(in),optional::MaxIteration
+        real*8,intent(in),optional::Precision,MinStepLength,WolfeConst1,WolfeConst2,Increment
+        p=c_null_ptr; ls=0; li=0; lr=0d0
+        if(present(Strong)) then; ls(1)=merge(1,0,Strong); p(1)=c_loc(ls(1)); end if
+        if(present(Warning)) then; ls(2)=merge(1,0,Warning); p(2)=c_loc(ls(2)); end if
+        if(present(MaxIteration)) then; li(1)=MaxIteration; p(3)=c_loc(li(1)); end if
+        if(present(Precision)) then; lr(1)=Precision; p(4)=c_loc(lr(1)); end if
+        if(present(MinStepLength)) then; lr(2)=MinStepLength; p(5)=c_loc(lr(2)); end if
+        if(present(WolfeConst1)) then; lr(3)=WolfeConst1; p(6)=c_loc(lr(3)); end if
+        if(present(WolfeConst2)) then; lr(4)=WolfeConst2; p(7)=c_loc(lr(4)); end if
+        if(present(Increment)) then; lr(5)=Increment; p(8)=c_loc(lr(5)); end if
+    end subroutine pack_common
+
+    !Batched L-BFGS on device-resident data: same keyword names and defaults as LBFGS
+    subroutine LBFGS_batched(objective, x_dev, batch, dim, d_dev, b_dev, ws_dev, ws_bytes, &
+    f_dev, iters_dev, status_dev, info, &
+    Memory, Strong, MaxIteration, Precision, MinStepLength, WolfeConst1, WolfeConst2, Increment)
+        integer,intent(in)::objective,batch,dim
+        type(c_ptr),intent(in)::x_dev,d_dev,b_dev,ws_dev,f_dev,iters_dev,status_dev
+        integer(c_size_t),intent(in)::ws_bytes
+        integer,intent(out)::info
+        integer,intent(in),optional::Memory,MaxIteration
+        logical,intent(in),optional::Strong
+        real*8,intent(in),optional::Precision,MinStepLength,WolfeConst1,WolfeConst2,Increment
+        type(fl_options)::o
+        call fl_default_options(o,FL_SOLVER_LBFGS)
+        if(present(Memory)) o%memory=Memory
+        if(present(Strong)) o%strong=merge(1,0,Strong)
+        if(present(MaxIteration)) o%max_iteration=MaxIteration
+        if(present(Precision)) o%precision=Precision
+        if(present(MinStepLength)) o%min_step_length=MinStepLength
+        if(present(WolfeConst1)) o%wolfe_c1=WolfeConst1
+        if(present(WolfeConst2)) o%wolfe_c2=WolfeConst2
+        if(present(Increment)) o%increment=Increment
+        info=fl_lbfgs_batched(objective,batch,dim,x_dev,d_dev,b_dev,o,ws_dev,ws_bytes,&
+            f_dev,c_null_ptr,iters_dev,status_dev,c_null_ptr,c_null_ptr,c_null_ptr)
+    end subroutine LBFGS_batched
+!------------------ End ------------------
+end module NonlinearOptimization

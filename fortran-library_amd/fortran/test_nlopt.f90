@@ -1,0 +1,67 @@
+!Fortran smoke test of the drop-in module, mirroring the optimiser section of the reference's
+!test/test.f90:330-413 (quartic sum x^4, dim = 10; "Correct routines should print close to 0").
+!Deterministic start x_i = 0.1 i instead of the reference's clock-seeded random_number(x).
+module quartic
+    implicit none
+contains
+    subroutine f(fx,x,dim)
+        real*8,intent(out)::fx
+        integer,intent(in)::dim
+        real*8,dimension(dim),intent(in)::x
+        integer::i
+        fx=0d0
+        do i=1,dim
+            fx=fx+x(i)**4
+        end do
+    end subroutine f
+    subroutine fd(fdx,x,dim)
+        integer,intent(in)::dim
+        real*8,dimension(dim),intent(out)::fdx
+        real*8,dimension(dim),intent(in)::x
+        integer::i
+        do i=1,dim
+            fdx(i)=4d0*x(i)**3
+        end do
+    end subroutine fd
+    integer function f_fd(fx,fdx,x,dim)
+        integer,intent(in)::dim
+        real*8,intent(out)::fx
+        real*8,dimension(dim),intent(out)::fdx
+        real*8,dimension(dim),intent(in)::x
+        integer::i
+        fx=0d0
+        do i=1,dim
+            fx=fx+x(i)**4
+            fdx(i)=4d0*x(i)**3
+        end do
+        f_fd=0
+    end function f_fd
+end module quartic
+
+program main
+    use FortranLibrary
+    use quartic
+    implicit none
+    integer,parameter::dim=10
+    integer::i
+    real*8,dimension(dim)::x
+    write(*,*)'Steepest descent'
+    call start(); call SteepestDescent(f,fd,x,dim,Warning=.false.,MaxIteration=300); write(*,'(A,ES24.16)')' SD ',norm2(x)
+    write(*,*)'Conjugate gradient'
+    call start(); call ConjugateGradient(f,fd,x,dim,Warning=.false.); write(*,'(A,ES24.16)')' CG-DY ',norm2(x)
+    call start(); call ConjugateGradient(f,fd,x,dim,Strong=.false.,Warning=.false.); write(*,'(A,ES24.16)')' CG-DY-Wolfe ',norm2(x)
+    call start(); call ConjugateGradient(f,fd,x,dim,f_fd=f_fd,Warning=.false.); write(*,'(A,ES24.16)')' CG-DY-f_fd ',norm2(x)
+    call start(); call ConjugateGradient(f,fd,x,dim,Method='PR',Warning=.false.); write(*,'(A,ES24.16)')' CG-PR ',norm2(x)
+    write(*,*)'L-BFGS'
+    call start(); call LBFGS(f,fd,x,dim,Warning=.false.); write(*,'(A,ES24.16)')' LBFGS ',norm2(x)
+    call start(); call LBFGS(f,fd,x,dim,Strong=.true.,Warning=.false.); write(*,'(A,ES24.16)')' LBFGS-Strong ',norm2(x)
+    call start(); call LBFGS(f,fd,x,dim,f_fd=f_fd,Memory=5,Warning=.false.); write(*,'(A,ES24.16)')' LBFGS-f_fd-M5 ',norm2(x)
+    write(*,*)'BFGS'
+    call start(); call BFGS(f,fd,x,dim,ExactStep=0,Warning=.false.); write(*,'(A,ES24.16)')' BFGS0 ',norm2(x)
+    call start(); call BFGS(f,fd,x,dim,ExactStep=0,f_fd=f_fd,Warning=.false.); write(*,'(A,ES24.16)')' BFGS0-f_fd ',norm2(x)
+    write(*,*)'Mission complete'
+contains
+    subroutine start()
+        do i=1,dim; x(i)=0.1d0*i; end do
+    end subroutine start
+end program main

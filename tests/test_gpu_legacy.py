@@ -161,3 +161,28 @@ def test_rci_batched_torch_objective_equals_fused_kernel():
         fused = {NLO.LBFGS_: NLO.LBFGS, NLO.CG: NLO.ConjugateGradient, NLO.BFGS_: NLO.BFGS}[solver]
         ref = fused(NLO.DIAGQUAD, x2, d, b, Precision=1e-6)
         assert torch.allclose(out["f"], ref["f"], rtol=1e-10, atol=0)
+
+
+def test_fortran_use_fortranlibrary_smoke():
+    """`use FortranLibrary` from Fortran (amdflang): the shim module forwards to libFL.so, the solver runs on the
+    GPU and calls the Fortran callbacks on the host.  Mirrors test/test.f90:330-413: residuals close to 0."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fortran-library_amd", "fortran", "test_nlopt")
+    if not os.path.exists(exe):
+        pytest.skip("Fortran smoke test not built (make -C fortran-library_amd/fortran)")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "Mission complete" in out.stdout
+    vals = {}
+    for line in out.stdout.splitlines():
+        parts = line.split()
+        if len(parts) == 2 and parts[0] not in ("Steepest", "Conjugate"):
+            try:
+                vals[parts[0]] = float(parts[1])
+            except ValueError:
+                pass
+    assert len(vals) == 10, out.stdout
+    for k, v in vals.items():
+        assert v < (0.2 if k == "SD" else 1e-3), (k, v)  # steepest descent on a quartic crawls; the rest reach ~1e-5
