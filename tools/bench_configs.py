@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Measure the other BASELINE.json configurations (C2-C5) on one MI355X: one JSON line each.
+
+Not the driver's bench (that is bench.py = the north-star headline); this records the numbers DESIGN.md quotes
+for the remaining rows of SURVEY.md section 8.  Same method: inputs generated on the device, one launch of the
+fused kernel per solve, HIP events on the launch stream, algorithmic bytes per SURVEY.md 8(d), CPU oracle
+(reference summation order, OpenMP one problem per thread on the cgroup's cores) on a bounded sample.
+usage: python tools/bench_configs.py [c2 c3 c4 c5] [--cpu-seconds 10]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "fortran-library_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import FortranLibrary.NonlinearOptimization as NLO
+import oracle_lib as O
+from bench import host_cores, cpu_model, SEED, HBM_PEAK_GBS
+
+dev = torch.device("cuda:0")
+
+
+def timed(fn, reps=2):
+    fn()
+    torch.cuda.synchronize()
+    ms = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    return out, sum(ms) / len(ms)
+
+
+def cpu_rate(call, S0, seconds, cores):
+    """iterations/s of the oracle: pilot on S0 problems, then a sample sized for `seconds` of wall time"""
+    t = time.perf_counter()
+    call(S0)
+    pilot = max(time.perf_counter() - t, 1e-3)
+    S = int(max(S0, S0 * seconds / pilot))
+    t = time.perf_counter()
+    r = call(S)
+    dt = time.perf_counter() - t
+    return float(r["iters"].sum()) / dt, S, dt, r
+
+
+def quad(B, n, klo, khi):
+    d = torch.empty(B, n, dtype=torch.float64, device=dev)
+    b = torch.empty(B, n, dtype=torch.float64, device=dev)
+    NLO.synth_diag_spectrum(SEED, d, klo, khi)
+    NLO.synth_uniform(SEED, b, -1.0, 1.0)
+    return d, b
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("configs", nargs="*", default=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--c4-batch", type=int, default=1024)
+    args = ap.parse_args()
+    cores = host_cores()
+    host = f"{cores} cores of {cpu_model()}"
+
+    if "c2" in args.configs:  # Batch 4096 independent Rosenbrock n=256, L-BFGS m=10
+        B, n, m = 4096, 256, 10
+        x0 = torch.empty(B, n, dtype=torch.float64, device=dev)
+        NLO.synth_uniform(SEED, x0, 0.9, 1.1)
+        ws = NLO.workspace(B, n, m, dev)
+        x = torch.empty_like(x0)
+
+        def run():
+            x.copy_(x0)
+            return NLO.LBFGS(NLO.ROSENBROCK, x, workspace_=ws, Precision=1e-10, MaxIteration=3000, Memory=m)
+        out, ms = timed(run, 5)
+        it = out["iters"].to(torch.int64)
+        k = torch.clamp(it - 1, min=0)
+        part = torch.clamp(k, max=m)
+        cnt = part * (part + 1) // 2 + torch.clamp(k - m, min=0) * m
+        algo = float((8 * n * (4 * cnt + 2 * k)).sum())
+        oo = O.defaults(precision=1e-10, maxit=3000, memory=m)
+        xh = x0.cpu().numpy()
+        rate, S, dt, ref = cpu_rate(lambda s: O.solve_batch(O.LBFGS, O.ROSENBROCK, xh[:min(s, B)], opts=oo, nthreads=cores),
+                                    4 * cores, args.cpu_seconds, cores)
+        S = min(S, B)
+        print(json.dumps({"config": "C2 L-BFGS m=10, Rosenbrock n=256, batch 4096, Precision 1e-10", "ms": ms,
+                          "iterations_per_s": float(it.sum()) / ms * 1e3, "iterations": int(it.sum()),
+                          "converged_fraction": float((out["status"] == 0).double().mean()),
+                          "algorithmic_GBps_two_loop": algo / ms / 1e6, "frac_of_8TBps": algo / ms / 1e6 / HBM_PEAK_GBS,
+                          "cpu_iterations_per_s": rate, "cpu": host, "cpu_sample": S,
+                          "max_abs_x_minus_1": float((x - 1).abs().max()),
+                          "final_f_abs_err_max_vs_cpu": float(np.max(np.abs(out["f"][:S].cpu().numpy() - ref["f"][:S])))}))
+
+    if "c3" in args.configs:  # Batch 65536 convex quadratics n=1024, Dai-Yuan CG
+        B, n = 65536, 1024
+        d, b = quad(B, n, 10.0, 1000.0)
+        x = torch.zeros(B, n, dtype=torch.float64, device=dev)
+
+        def run():
+            x.zero_()
+            return NLO.ConjugateGradient(NLO.DIAGQUAD, x, d, b, Precision=1e-6, MaxIteration=3000)
+        out, ms = timed(run, 3)
+        it = out["iters"].to(torch.int64)
+        nfg = (out["nf"].to(torch.int64) + out["ng"].to(torch.int64))
+        # streaming model: trial 32n + objective 16n bytes per f+g evaluation pair, DY update 32n per iteration
+        algo = float((8 * n * (3 * nfg + 4 * it)).sum())
+        oo = O.defaults(precision=1e-6, maxit=3000, c2=0.45)
+        dh, bh = d[:4096].cpu().numpy(), b[:4096].cpu().numpy()
+        rate, S, dt, ref = cpu_rate(lambda s: O.solve_batch(O.CG, O.DIAGQUAD, np.zeros((min(s, 4096), n)), d=dh[:min(s, 4096)],
+                                                            b=bh[:min(s, 4096)], opts=oo, nthreads=cores),
+                                    4 * cores, args.cpu_seconds, cores)
+        S = min(S, 4096)
+        print(json.dumps({"config": "C3 CG Dai-Yuan, diagonal quadratics n=1024 kappa in [10,1000], batch 65536, Precision 1e-6",
+                          "ms": ms, "iterations_per_s": float(it.sum()) / ms * 1e3, "iterations": int(it.sum()),
+                          "converged_fraction": float((out["status"] == 0).double().mean()),
+                          "algorithmic_GBps_streaming_model": algo / ms / 1e6,
+                          "note": "every CG vector lives in registers: the kernel moves no HBM bytes per iteration",
+                          "cpu_iterations_per_s": rate, "cpu": host, "cpu_sample": S,
+                          "final_f_rel_err_max_vs_cpu": float(np.max(np.abs(out["f"][:S].cpu().numpy() - ref["f"][:S])
+                                                                     / np.abs(ref["f"][:S])))}))
+
+    if "c4" in args.configs:  # Batch 1024 problems n=4096, full dense BFGS, fixed K=20 iterations
+        B, n, K = args.c4_batch, 4096, 20
+        d, b = quad(B, n, 10.0, 100.0)
+        x = torch.zeros(B, n, dtype=torch.float64, device=dev)
+        ws = NLO.bfgs_workspace(B, n, dev)
+
+        def run():
+            x.zero_()
+            return NLO.BFGS(NLO.DIAGQUAD, x, d, b, workspace_=ws, Precision=1e-12, MaxIteration=K - 1)
+        out, ms = timed(run, 2)
+        it = out["iters"].to(torch.int64)
+        # rank-2 form: per update 8n^2 (q = H y) + 16n^2 (read H, write H'); the first update only writes 8n^2
+        upd = torch.clamp(it - 1, min=0)
+        algo = float((upd * 24 * n * n + (it > 0) * 8 * n * n).sum())
+        Bc = 2 * cores  # the CPU oracle at n=4096 is O(n^2) per update too (update_form 1); as-written form 0 is O(n^3)
+        oo = O.defaults(precision=1e-12, maxit=K - 1, exact_step=0)
+        dh, bh = d[:Bc].cpu().numpy(), b[:Bc].cpu().numpy()
+        t = time.perf_counter()
+        ref = O.solve_batch(O.BFGS, O.DIAGQUAD, np.zeros((Bc, n)), d=dh, b=bh, opts=oo, bfgs_form=1, nthreads=cores)
+        dt = time.perf_counter() - t
+        print(json.dumps({"config": f"C4 dense BFGS (ExactStep=0), diagonal quadratics n=4096 kappa in [10,100], batch {B}, "
+                                    f"fixed {K} iterations", "ms": ms, "iterations_per_s": float(it.sum()) / ms * 1e3,
+                          "iterations": int(it.sum()), "update_form": "rank-2 streaming (24 n^2 B per iteration)",
+                          "algorithmic_GBps": algo / ms / 1e6, "frac_of_8TBps": algo / ms / 1e6 / HBM_PEAK_GBS,
+                          "inverse_hessian_bytes": B * n * n * 8,
+                          "cpu_iterations_per_s_rank2_form": float(ref["iters"].sum()) / dt, "cpu": host, "cpu_sample": Bc,
+                          "final_f_rel_err_max_vs_cpu_tree_order": None}))
+
+    if "c5" in args.configs:  # aug-Lagrangian wrapping L-BFGS, batch 8192 n=512, 8 equality constraints
+        B, n, M, m = 8192, 512, 8, 10
+        d, b = quad(B, n, 2.0, 10.0)
+        x0 = torch.empty(B, n, dtype=torch.float64, device=dev)
+        NLO.synth_uniform(SEED + 7, x0, 0.05, 0.15)
+        x = torch.empty_like(x0)
+        ws = NLO.workspace(B, n, m, dev)
+
+        def run():
+            x.copy_(x0)
+            return NLO.AugmentedLagrangian(NLO.DIAGQUAD, x, M, d, b, UnconstrainedSolver="LBFGS", workspace_=ws,
+                                           Precision=1e-10, Memory=m)
+        out, ms = timed(run, 2)
+        it = out["iters"].to(torch.int64)
+        oo = O.defaults(precision=1e-10, memory=m)
+        Bc = 4 * cores
+        t = time.perf_counter()
+        ref = O.auglag_batch(O.LBFGS, O.DIAGQUAD, x0[:Bc].cpu().numpy(), M, d=d[:Bc].cpu().numpy(), b=b[:Bc].cpu().numpy(),
+                             opts=oo, nthreads=cores)
+        dt = time.perf_counter() - t
+        fx = (0.5 * (d * x * x).sum(1) - (b * x).sum(1))[:Bc].cpu().numpy()
+        print(json.dumps({"config": "C5 augmented Lagrangian + L-BFGS m=10, n=512, 8 block-sphere constraints, batch 8192, "
+                                    "Precision 1e-10", "ms": ms, "inner_iterations_per_s": float(it.sum()) / ms * 1e3,
+                          "inner_iterations": int(it.sum()), "outer_iterations_mean": float(out["outer"].double().mean()),
+                          "f_evals": int(out["nf"].to(torch.int64).sum()),
+                          "converged_fraction": float((out["status"] == 0).double().mean()),
+                          "cnorm_max": float(out["cnorm2"].max().sqrt()),
+                          "cpu_inner_iterations_per_s": float(ref["iters"].sum()) / dt, "cpu": host, "cpu_sample": Bc,
+                          "final_f_rel_err_max_vs_cpu": float(np.max(np.abs(fx - ref["f"]) / np.abs(ref["f"])))}))
+
+
+if __name__ == "__main__":
+    main()
