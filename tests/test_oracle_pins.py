@@ -111,3 +111,20 @@ def test_bfgs_rosenbrock_n256_probe():
     r = O.solve_batch(O.BFGS, O.ROSENBROCK, _rosen_start(256), opts=O.defaults(exact_step=0))
     assert abs(r["f"][0] - 6.4e-27) < 0.05e-27
     assert (r["nf"][0] + 1, r["ng"][0]) == (6935, 5854)
+
+
+def test_fixture_file_agrees_with_pins():
+    """tests/golden/baseline_probes.json (tools/make_golden.py) carries the same BASELINE.md numbers"""
+    import json
+    cases = {c["name"]: c for c in json.load(open(os.path.join(os.path.dirname(__file__), "golden", "baseline_probes.json")))["cases"]}
+    assert cases["lbfgs_rosen_n256_maxit1000"]["f"] == 4.2659329580565036e01
+    assert cases["auglag_lbfgs_n512_m8"]["f"] == -23.331108193268726
+    n = 1024
+    i = np.arange(1, n + 1).astype(float)
+    for name in ("cgdy_quad_n1024_k1000", "lbfgs_quad_n1024_k10", "cgpr_quad_n1024_k10"):
+        c = cases[name]
+        d = 1 + (c["kappa"] - 1) * (i - 1) / (n - 1)
+        solver = O.LBFGS if c["solver"] == "LBFGS" else O.CG
+        o = O.defaults(c2=0.45 if solver == O.CG else 0.9, method=1 if c.get("method") == "PR" else 0)
+        r = O.solve_batch(solver, O.DIAGQUAD, np.zeros(n), d=d, b=np.sin(i), opts=o)
+        assert _close(r["f"][0], c["f"]) and (r["nf"][0] + 1, r["ng"][0]) == (c["nf_plus_1"], c["ng"])
