@@ -202,6 +202,25 @@ def AugmentedLagrangian(objective, x, M, d=None, b=None, UnconstrainedSolver="LB
     return out
 
 
+FL.fl_bfgs_update_gemm_workspace_bytes.argtypes = [C.c_int, C.c_int]
+FL.fl_bfgs_update_gemm_workspace_bytes.restype = C.c_size_t
+FL.fl_bfgs_update_gemm_batched.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, _vp, C.c_size_t, _vp]
+
+
+def bfgs_update_gemm(H, s, y, chunk=None, workspace_=None):
+    """H <- U^T (H U) + rho s s^T exactly as the reference writes it (two dense products on f64 MFMA).
+    H: [batch, n, ld] column-major inverse Hessians (solver layout, ld = threads*ept), in place."""
+    import torch
+    B, n = s.shape
+    c = chunk if chunk else B
+    ws = workspace_
+    if ws is None:
+        ws = torch.empty(FL.fl_bfgs_update_gemm_workspace_bytes(c, n) // 8, dtype=torch.float64, device=s.device)
+    _check(FL.fl_bfgs_update_gemm_batched(B, n, _ptr(H), _ptr(s), _ptr(y), _ptr(ws), ws.numel() * 8, _stream()),
+           "fl_bfgs_update_gemm_batched")
+    return ws
+
+
 FL.fl_rci_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.POINTER(Options), _vp]
 FL.fl_rci_step.argtypes = [_vp, _dp, _dp, _dp, _ip]
 FL.fl_rci_results.argtypes = [_vp, _dp, _dp, _ip, _ip, _ip, _ip]

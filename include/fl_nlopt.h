@@ -129,6 +129,18 @@ int fl_bfgs_batched(int objective, int batch, int n, double *x_dev, const double
                     const fl_options *opt, void *workspace_dev, size_t workspace_bytes, double *f_dev, double *gg_dev,
                     int32_t *iters_dev, int32_t *status_dev, int32_t *nf_dev, int32_t *ng_dev, void *stream);
 
+/* The BFGS inverse-Hessian update AS THE REFERENCE WRITES IT: U = I - rho y s^T, rho = 1/(y.s),
+ * H <- matmul(transpose(U), matmul(H, U)) + rho s s^T  (NO.f90:958-962; LinearAlgebra.f90:105-114
+ * vector_direct_product) -- two dense n^3 products on the f64 matrix cores (v_mfma_f64_16x16x4_f64),
+ * 4 n^3 flop per problem.  H_dev: [batch][n][ld] column-major inverse Hessians in the solver's layout
+ * (ld = threads*ept of fl_reduction_geometry), updated in place; s_dev, y_dev [batch][n].
+ * workspace: one n x ld product buffer (+ n + 1 doubles) per problem of a chunk; the batch is processed
+ * in chunks of workspace_bytes / fl_bfgs_update_gemm_workspace_bytes(1, n) problems.
+ * (fl_bfgs_batched itself uses the algebraically equal O(n^2) rank-2 form.) */
+size_t fl_bfgs_update_gemm_workspace_bytes(int chunk, int n);
+int fl_bfgs_update_gemm_batched(int batch, int n, double *H_dev, const double *s_dev, const double *y_dev,
+                                void *workspace_dev, size_t workspace_bytes, void *stream);
+
 /* Augmented Lagrangian for equality constraints (subroutine AugmentedLagrangian, NO.f90:2005-2241;
  * C++ binding cpp/NonlinearOptimization.hpp:367-392) around solver = FL_SOLVER_LBFGS (NO.f90:2150-2167)
  * or FL_SOLVER_CG (NO.f90:2168-2185).  Built-in constraint family: m block spheres

@@ -764,6 +764,16 @@ static void bfgs_update(int n, double *H, double *U, const double *s, const doub
     }
 }
 
+/* one update of a column-major n x n inverse Hessian (rho computed here), for the tests of the
+ * stand-alone GPU update kernels: form 0 = the reference's two matmuls, form 1 = rank-2 */
+void flo_bfgs_update(int n, double *H, const double *s, const double *y, int form)
+{
+    double *U = (double *)malloc(sizeof(double) * (size_t)n * n);
+    const double rho = 1.0 / flo_dot(n, y, s);
+    bfgs_update(n, H, U, s, y, rho, 0, 0.0, form);
+    free(U);
+}
+
 /* BFGS, NO.f90:632-1022 */
 void flo_bfgs(flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, flo_fdd_t fdd, double *x, int n, const flo_opts *o,
               int update_form, void *ctx, flo_stats *st)

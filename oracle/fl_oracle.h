@@ -99,6 +99,10 @@ void flo_augmented_lagrangian(flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, flo_c_t c,
                               int m, int solver, double *lambda, double miu0, const flo_opts *o, void *ctx,
                               flo_stats *st, int *outer_iters, double *cnorm2);
 
+/* one BFGS update of a column-major inverse Hessian: form 0 = U^T (H U) + rho s s^T as two
+ * matmuls (NO.f90:958-962), form 1 = the rank-2 expression */
+void flo_bfgs_update(int n, double *H, const double *s, const double *y, int form);
+
 /* dense helpers restated from LinearAlgebra.f90 (column-major) */
 int flo_dpotri_lower(double *A, int n); /* My_dpotri LA.f90:798 : dpotrf+dpotri 'L'; returns info */
 void flo_syL2U(double *A, int n);       /* dsyL2U LA.f90:260 */

@@ -1,0 +1,56 @@
+"""The as-written BFGS update (two dense matmuls, NO.f90:958-962) on the f64 matrix cores against the
+oracle's restatement of the same two matmuls (sequential sums) and against the rank-2 form.
+MFMA accumulates with fused multiply-adds and its own k order, so this is a tolerance test (relative to
+the magnitude of the products), on ASYMMETRIC data so that a transposed fragment map cannot pass."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.mark.parametrize("n", [10, 64, 130, 257, 600])
+def test_two_gemm_update_matches_reference_matmuls(n):
+    import FortranLibrary.NonlinearOptimization as NLO
+    lib = O.lib()
+    dp = C.POINTER(C.c_double)
+    lib.flo_bfgs_update.argtypes = [C.c_int, dp, dp, dp, C.c_int]
+    lib.flo_set_sum_mode(O.SEQ, 64, 2)
+    rng = np.random.default_rng(n)
+    B = 3
+    T, E = NLO.reduction_geometry(n)
+    ld = T * E
+    Hs = rng.standard_normal((B, n, n))  # asymmetric on purpose; column-major: Hs[b, col, row]
+    s = rng.standard_normal((B, n))
+    y = s * rng.uniform(0.5, 2.0, (B, n)) + 0.1 * rng.standard_normal((B, n))
+    Hpad = np.zeros((B, n, ld))
+    Hpad[:, :, :n] = Hs
+    dev = torch.device("cuda:0")
+    Hd = torch.tensor(Hpad, device=dev)
+    NLO.bfgs_update_gemm(Hd, torch.tensor(s, device=dev), torch.tensor(y, device=dev), chunk=2)
+    torch.cuda.synchronize()
+    got = Hd.cpu().numpy()[:, :, :n]
+    assert np.all(Hd.cpu().numpy()[:, :, n:] == 0.0)  # padding untouched
+    for k in range(B):
+        ref0 = np.ascontiguousarray(Hs[k]).copy()
+        lib.flo_bfgs_update(n, ref0.ctypes.data_as(dp), s[k].ctypes.data_as(dp), y[k].ctypes.data_as(dp), 0)
+        ref1 = np.ascontiguousarray(Hs[k]).copy()
+        # the rank-2 form assumes a symmetric H: compare it on the symmetrised matrix below instead
+        scale = np.abs(ref0).max()
+        assert np.max(np.abs(got[k] - ref0)) <= 1e-12 * scale * n, (n, k)
+    # symmetric H: both forms of the oracle and the GPU agree
+    A = rng.standard_normal((n, n))
+    Hsym = A @ A.T / n + np.eye(n)
+    Hpad = np.zeros((1, n, ld))
+    Hpad[0, :, :n] = Hsym
+    Hd = torch.tensor(Hpad, device=dev)
+    NLO.bfgs_update_gemm(Hd, torch.tensor(s[:1], device=dev), torch.tensor(y[:1], device=dev))
+    torch.cuda.synchronize()
+    r1 = Hsym.copy()
+    lib.flo_bfgs_update(n, r1.ctypes.data_as(dp), s[0].ctypes.data_as(dp), y[0].ctypes.data_as(dp), 1)
+    got = Hd.cpu().numpy()[0, :, :n]
+    assert np.max(np.abs(got - r1)) <= 1e-11 * np.abs(r1).max() * n

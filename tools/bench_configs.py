@@ -154,6 +154,24 @@ def main():
                           "cpu_iterations_per_s_rank2_form": float(ref["iters"].sum()) / dt, "cpu": host, "cpu_sample": Bc,
                           "final_f_rel_err_max_vs_cpu_tree_order": None}))
 
+    if "c4gemm" in args.configs:  # the as-written two-matmul update on the f64 matrix cores
+        B, n = 16, 4096
+        T, E = NLO.reduction_geometry(n)
+        ld = T * E
+        H = torch.zeros(B, n, ld, dtype=torch.float64, device=dev)
+        H[:, torch.arange(n), torch.arange(n)] = 1.0
+        H[:, :, :n] += 0.01 * torch.randn(B, n, n, dtype=torch.float64, device=dev)
+        s = torch.randn(B, n, dtype=torch.float64, device=dev)
+        y = s * (1 + torch.rand(B, n, dtype=torch.float64, device=dev)) 
+        ws = NLO.bfgs_update_gemm(H, s, y)
+        out, ms = timed(lambda: NLO.bfgs_update_gemm(H, s, y, workspace_=ws), 3)
+        flop = 4.0 * n ** 3 * B
+        PEAK = 78.6  # TFLOP/s FP64 matrix, AMD datasheet; not in the local guides
+        print(json.dumps({"config": f"C4-gemm BFGS update as written (2 x n^3 matmul on v_mfma_f64_16x16x4_f64), n=4096, {B} problems",
+                          "ms": ms, "TFLOPs": flop / ms / 1e9, "peak_TFLOPs_datasheet": PEAK, "frac": flop / ms / 1e9 / PEAK,
+                          "ms_per_problem_update": ms / B,
+                          "rank2_form_ms_per_problem_update_at_5.6TBps": 24.0 * n * n * 8 / 5.6e12 * 1e3 / 8}))
+
     if "c5" in args.configs:  # aug-Lagrangian wrapping L-BFGS, batch 8192 n=512, 8 equality constraints
         B, n, M, m = 8192, 512, 8, 10
         d, b = quad(B, n, 2.0, 10.0)
