@@ -17,6 +17,8 @@
 #include "fl_device.hpp"
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <string>
 #include <new>
 #include <vector>
 
@@ -221,8 +223,22 @@ typedef int (*fdd_cb)(double *, const double *, const int &);
 
 // One problem, host callbacks: the machine steps on the GPU, f / f' are evaluated by the caller's
 // code on the host exactly when the reference would call them (request bits).  Returns the status.
-static int legacy_solve(int solver, const char *name, f_cb f, fd_cb fd, ffd_cb f_fd, double *x, int n,
-                        const fl_options &o, int warn)
+struct HostObjective { // the caller's code, evaluated on the host when the machine asks for it
+    std::function<void(double &, const double *, int)> f;
+    std::function<void(double *, const double *, int)> fd;
+    std::function<void(double &, double *, const double *, int)> f_fd; // empty = f_fd absent
+};
+static HostObjective host_objective(f_cb f, fd_cb fd, ffd_cb f_fd)
+{
+    HostObjective ob;
+    ob.f = [f](double &fx, const double *x, int n) { f(fx, x, n); };
+    ob.fd = [fd](double *g, const double *x, int n) { fd(g, x, n); };
+    if (f_fd) ob.f_fd = [f_fd](double &fx, double *g, const double *x, int n) { (void)f_fd(fx, g, x, n); };
+    return ob;
+}
+
+static int legacy_solve(int solver, const char *name, const HostObjective &ob, double *x, int n, const fl_options &o,
+                        int warn)
 {
     fl_rci *h = nullptr;
     int rc = fl_rci_create(&h, solver, 1, n, &o, nullptr);
@@ -247,11 +263,11 @@ static int legacy_solve(int solver, const char *name, f_cb f, fd_cb fd, ffd_cb f
         if (!(rq & FL_REQ_SAME))
             if (hipMemcpy(x, xd, sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
         const bool wf = rq & FL_REQ_F, wg = rq & FL_REQ_G;
-        if (wf && wg && f_fd) {
-            (void)f_fd(fx, g.data(), x, n); // integer return value is ignored like the reference does (NO.f90:437)
+        if (wf && wg && ob.f_fd) {
+            ob.f_fd(fx, g.data(), x, n); // the integer return value is ignored like the reference does (NO.f90:437)
         } else {
-            if (wf) f(fx, x, n);
-            if (wg) fd(g.data(), x, n);
+            if (wf) ob.f(fx, x, n);
+            if (wg) ob.fd(g.data(), x, n);
         }
         if (wf) ok = ok && hipMemcpy(fdv, &fx, sizeof fx, hipMemcpyHostToDevice) == hipSuccess;
         if (wg) ok = ok && hipMemcpy(gd, g.data(), sizeof(double) * n, hipMemcpyHostToDevice) == hipSuccess;
@@ -317,7 +333,7 @@ void __nonlinearoptimization_MOD_steepestdescent(f_cb f, fd_cb fd, double *x, co
     fl_options o;
     legacy_options(o, FL_SOLVER_SD, Strong, MaxIteration, Precision, MinStepLength, WolfeConst1, WolfeConst2,
                    Increment, f_fd);
-    legacy_solve(FL_SOLVER_SD, "steepest descent", f, fd, f_fd, x, *dim, o, warn_of(Warning));
+    legacy_solve(FL_SOLVER_SD, "steepest descent", host_objective(f, fd, f_fd), x, *dim, o, warn_of(Warning));
 }
 
 // subroutine ConjugateGradient(f,fd,x,dim,Method,f_fd,Strong,...)  NO.f90:193 ; hpp:309-324
@@ -333,7 +349,7 @@ void __nonlinearoptimization_MOD_conjugategradient(f_cb f, fd_cb fd, double *x, 
         return;
     }
     o.cg_method = m;
-    legacy_solve(FL_SOLVER_CG, "conjugate gradient", f, fd, f_fd, x, *dim, o, warn_of(Warning));
+    legacy_solve(FL_SOLVER_CG, "conjugate gradient", host_objective(f, fd, f_fd), x, *dim, o, warn_of(Warning));
 }
 
 // subroutine ConjugateGradient_basic(...)  NO.f90:2249-2346 ; hpp:294-307: every argument required,
@@ -351,7 +367,7 @@ void __nonlinearoptimization_MOD_conjugategradient_basic(f_cb f, fd_cb fd, doubl
         return;
     }
     o.cg_method = m;
-    legacy_solve(FL_SOLVER_CG, "conjugate gradient", f, fd, nullptr, x, *dim, o, warn_of(Warning));
+    legacy_solve(FL_SOLVER_CG, "conjugate gradient", host_objective(f, fd, nullptr), x, *dim, o, warn_of(Warning));
 }
 
 // subroutine LBFGS(f,fd,x,dim,Memory,f_fd,Strong,...)  NO.f90:398 (no C++ wrapper in the reference header)
@@ -362,7 +378,7 @@ void __nonlinearoptimization_MOD_lbfgs(f_cb f, fd_cb fd, double *x, const int *d
     legacy_options(o, FL_SOLVER_LBFGS, Strong, MaxIteration, Precision, MinStepLength, WolfeConst1, WolfeConst2,
                    Increment, f_fd);
     if (Memory) o.memory = *Memory;
-    legacy_solve(FL_SOLVER_LBFGS, "L-BFGS", f, fd, f_fd, x, *dim, o, warn_of(Warning));
+    legacy_solve(FL_SOLVER_LBFGS, "L-BFGS", host_objective(f, fd, f_fd), x, *dim, o, warn_of(Warning));
 }
 
 // subroutine BFGS(f,fd,x,dim,fdd,ExactStep,f_fd,Strong,...)  NO.f90:632 ; hpp:326-342.
@@ -380,7 +396,123 @@ void __nonlinearoptimization_MOD_bfgs(f_cb f, fd_cb fd, double *x, const int *di
     if (freq > 0 && warn_of(Warning))
         std::printf(" BFGS (MI355X): exact Hessian refresh (ExactStep=%d) is not available on the device path;"
                     " continuing with quasi-Newton updates only (ExactStep=0)\n", freq);
-    legacy_solve(FL_SOLVER_BFGS, "BFGS", f, fd, f_fd, x, *dim, o, warn_of(Warning));
+    legacy_solve(FL_SOLVER_BFGS, "BFGS", host_objective(f, fd, f_fd), x, *dim, o, warn_of(Warning));
+}
+
+// subroutine AugmentedLagrangian(f,fd,c,cd,x,N,M,UnconstrainedSolver,lambda0,miu0,fdd,cdd,ExactStep,Memory,Method,
+// f_fd,Strong,...)  NO.f90:2005-2241 ; hpp:367-392.  The outer loop and the wrappers L, Ld, L_Ld (NO.f90:2193-2228:
+// compositions of the caller's f, fd, c, cd -- part of the objective evaluation, O(N M) on the host like the
+// callbacks themselves) follow the reference line by line; every inner solve runs on the GPU through the same
+// reverse-communication path as the entry points above.  Solvers: 'LBFGS', 'ConjugateGradient', 'BFGS'
+// (quasi-Newton branch, see bfgs above); 'NewtonRaphson' is not on the device path.
+typedef void (*c_cb)(double *, const double *, const int &, const int &);
+typedef void (*cd_cb)(double *, const double *, const int &, const int &);
+typedef int (*cdd_cb)(double *, const double *, const int &, const int &);
+
+void __nonlinearoptimization_MOD_augmentedlagrangian(f_cb f, fd_cb fd, c_cb c, cd_cb cd, double *x, const int *N,
+                                                     const int *M, const char *UnconstrainedSolver,
+                                                     const double *lambda0, const double *miu0, fdd_cb fdd, cdd_cb cdd,
+                                                     const int *ExactStep, const int *Memory, const char *Method,
+                                                     ffd_cb f_fd, FL_LEGACY_COMMON, int len_solver, int len_method)
+{
+    (void)fdd;
+    (void)cdd;
+    const int n = *N, m = *M;
+    std::string solver = UnconstrainedSolver ? std::string(UnconstrainedSolver, (size_t)len_solver) : "BFGS";
+    while (!solver.empty() && solver.back() == ' ') solver.pop_back();
+    const int warn = warn_of(Warning);
+    int sv;
+    if (solver == "LBFGS") sv = FL_SOLVER_LBFGS;
+    else if (solver == "ConjugateGradient") sv = FL_SOLVER_CG;
+    else if (solver == "BFGS") sv = FL_SOLVER_BFGS;
+    else { // NO.f90:2186 (NewtonRaphson: not on the device path)
+        std::printf(" Program abort: unsupported unconstrained solver %s\n", solver.c_str());
+        return;
+    }
+    fl_options o;
+    legacy_options(o, sv, Strong, MaxIteration, Precision, MinStepLength, WolfeConst1, WolfeConst2, Increment, nullptr);
+    if (!WolfeConst2) o.wolfe_c2 = (sv == FL_SOLVER_CG) ? 0.45 : 0.9; // NO.f90:2053-2062
+    if (Memory) o.memory = *Memory;
+    o.fused_f_fd = 1; // the inner solver always receives f_fd=L_Ld (NO.f90:2134, 2153, 2171)
+    if (sv == FL_SOLVER_CG) {
+        const int mth = cg_method_of(Method, Method ? len_method : 0);
+        if (mth < 0) {
+            std::printf(" Program abort: unsupported conjugate gradient method %.*s\n", len_method, Method);
+            return;
+        }
+        o.cg_method = mth;
+    }
+    if (sv == FL_SOLVER_BFGS && (ExactStep ? *ExactStep : 20) > 0 && warn)
+        std::printf(" BFGS (MI355X): exact Hessian refresh is not available on the device path; quasi-Newton updates only\n");
+    const int maxit = MaxIteration ? *MaxIteration : 1000;
+    const double tol = Precision ? *Precision : 1e-15, incrmt = Increment ? *Increment : 1.05;
+    std::vector<double> lambda(m, 0.0), cx(m), cdx((size_t)n * m), v(m);
+    if (lambda0) lambda.assign(lambda0, lambda0 + m);
+    double miu = miu0 ? (*miu0 > 1.0 ? *miu0 : 1.0) : 1.0; // miu=max(1d0,miu0)
+    auto seqdot = [](int k, const double *a, const double *b) {
+        double t = 0.0;
+        for (int i = 0; i < k; ++i) t = t + a[i] * b[i];
+        return t;
+    };
+    auto lx = [&](double &Lx) { Lx = Lx - seqdot(m, lambda.data(), cx.data()) + miu / 2.0 * seqdot(m, cx.data(), cx.data()); };
+    auto ldx = [&](double *Ldx) { // Ldx=Ldx+matmul(cdx,miu*cx-lambda)
+        for (int j = 0; j < m; ++j) v[j] = miu * cx[j] - lambda[j];
+        for (int i = 0; i < n; ++i) {
+            double t = 0.0;
+            for (int j = 0; j < m; ++j) t = t + cdx[(size_t)j * n + i] * v[j];
+            Ldx[i] = Ldx[i] + t;
+        }
+    };
+    HostObjective ob;
+    ob.f = [&](double &Lx, const double *xx, int nn) { // L, NO.f90:2193-2199
+        f(Lx, xx, nn);
+        c(cx.data(), xx, m, nn);
+        lx(Lx);
+    };
+    ob.fd = [&](double *Ldx, const double *xx, int nn) { // Ld, NO.f90:2200-2206
+        fd(Ldx, xx, nn);
+        c(cx.data(), xx, m, nn);
+        cd(cdx.data(), xx, m, nn);
+        ldx(Ldx);
+    };
+    ob.f_fd = [&](double &Lx, double *Ldx, const double *xx, int nn) { // L_Ld / L_Ld_fdwithf, NO.f90:2207-2228
+        if (f_fd) {
+            (void)f_fd(Lx, Ldx, xx, nn);
+            c(cx.data(), xx, m, nn);
+            lx(Lx);
+            cd(cdx.data(), xx, m, nn);
+        } else {
+            f(Lx, xx, nn);
+            c(cx.data(), xx, m, nn);
+            lx(Lx);
+            fd(Ldx, xx, nn);
+            cd(cdx.data(), xx, m, nn);
+        }
+        ldx(Ldx);
+    };
+    const char *names[] = {"steepest descent", "conjugate gradient", "L-BFGS", "BFGS"};
+    int it = 1;
+    for (; it <= maxit; ++it) {
+        if (legacy_solve(sv, names[sv], ob, x, n, o, warn) < 0) return;
+        c(cx.data(), x, m, n);
+        if (seqdot(m, cx.data(), cx.data()) < tol * tol) break; // if(dot_product(cx,cx)<tolsq) exit
+        for (int j = 0; j < m; ++j) lambda[j] = lambda[j] - miu * cx[j];
+        miu = miu * incrmt;
+    }
+    if (it > maxit && warn)
+        std::printf(" Failed augmented Lagrangian: max iteration exceeded!\n Euclidean norm of constraint violation = %24.16E\n",
+                    sqrt(seqdot(m, cx.data(), cx.data())));
+}
+void nonlinearoptimization_mp_augmentedlagrangian_(f_cb f, fd_cb fd, c_cb c, cd_cb cd, double *x, const int *N,
+                                                   const int *M, const char *UnconstrainedSolver,
+                                                   const double *lambda0, const double *miu0, fdd_cb fdd, cdd_cb cdd,
+                                                   const int *ExactStep, const int *Memory, const char *Method,
+                                                   ffd_cb f_fd, FL_LEGACY_COMMON, int len_solver, int len_method)
+{
+    __nonlinearoptimization_MOD_augmentedlagrangian(f, fd, c, cd, x, N, M, UnconstrainedSolver, lambda0, miu0, fdd, cdd,
+                                                    ExactStep, Memory, Method, f_fd, Strong, Warning, MaxIteration,
+                                                    Precision, MinStepLength, WolfeConst1, WolfeConst2, Increment,
+                                                    len_solver, len_method);
 }
 
 // ifort manglings of the same procedures (cpp/NonlinearOptimization.hpp:11-123)

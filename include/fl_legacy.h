@@ -8,6 +8,7 @@
  *   __nonlinearoptimization_MOD_conjugategradient_basic  cpp/NonlinearOptimization.hpp:294-307   (NO.f90:2249)
  *   __nonlinearoptimization_MOD_conjugategradient        cpp/NonlinearOptimization.hpp:309-324   (NO.f90:193)
  *   __nonlinearoptimization_MOD_bfgs                     cpp/NonlinearOptimization.hpp:326-342   (NO.f90:632)
+ *   __nonlinearoptimization_MOD_augmentedlagrangian      cpp/NonlinearOptimization.hpp:367-392   (NO.f90:2005)
  *   __nonlinearoptimization_MOD_lbfgs                    (Fortran only in the reference)          (NO.f90:398)
  *   nonlinearoptimization_mp_*_                          the ifort manglings, hpp:11-123
  * Conventions are the reference's (cpp/README.md:11-18): every argument by reference, an absent
@@ -17,7 +18,10 @@
  * x is the only result (in/out), warnings go to stdout when Warning is true, like the reference.
  * Differences: an unknown Method prints the reference's message and returns instead of `stop`;
  * BFGS runs the ExactStep<=0 branch (ExactStep>0 is announced and ignored: not on the device yet).
- * NewtonRaphson / TrustRegion / AugmentedLagrangian legacy symbols are not exported.
+ * AugmentedLagrangian: 'LBFGS', 'ConjugateGradient', 'BFGS' inner solvers ('NewtonRaphson' is refused with
+ * the reference's "unsupported unconstrained solver" message); the wrappers L, Ld, L_Ld that compose the
+ * caller's f, fd, c, cd (NO.f90:2193-2228) run on the host next to those callbacks, every inner solve on the GPU.
+ * NewtonRaphson / TrustRegion legacy symbols are not exported.
  */
 #ifndef FL_LEGACY_H
 #define FL_LEGACY_H
@@ -46,6 +50,22 @@ void __nonlinearoptimization_MOD_lbfgs(fl_f_cb f, fl_fd_cb fd, double *x, const 
                                        fl_f_fd_cb f_fd, FL_LEGACY_COMMON_ARGS);
 void __nonlinearoptimization_MOD_bfgs(fl_f_cb f, fl_fd_cb fd, double *x, const int *dim, fl_fdd_cb fdd,
                                       const int *ExactStep, fl_f_fd_cb f_fd, FL_LEGACY_COMMON_ARGS);
+
+typedef void (*fl_c_cb)(double *cx, const double *x, const int *M, const int *N);    /* subroutine c(c(x),x,M,N)    */
+typedef void (*fl_cd_cb)(double *cdx, const double *x, const int *M, const int *N);  /* subroutine cd(c'(x),x,M,N): N x M */
+typedef int (*fl_cdd_cb)(double *cddx, const double *x, const int *M, const int *N); /* integer function cdd         */
+void __nonlinearoptimization_MOD_augmentedlagrangian(fl_f_cb f, fl_fd_cb fd, fl_c_cb c, fl_cd_cb cd, double *x,
+                                                     const int *N, const int *M, const char *UnconstrainedSolver,
+                                                     const double *lambda0, const double *miu0, fl_fdd_cb fdd,
+                                                     fl_cdd_cb cdd, const int *ExactStep, const int *Memory,
+                                                     const char *Method, fl_f_fd_cb f_fd, FL_LEGACY_COMMON_ARGS,
+                                                     int len_UnconstrainedSolver, int len_Method);
+void nonlinearoptimization_mp_augmentedlagrangian_(fl_f_cb f, fl_fd_cb fd, fl_c_cb c, fl_cd_cb cd, double *x,
+                                                   const int *N, const int *M, const char *UnconstrainedSolver,
+                                                   const double *lambda0, const double *miu0, fl_fdd_cb fdd,
+                                                   fl_cdd_cb cdd, const int *ExactStep, const int *Memory,
+                                                   const char *Method, fl_f_fd_cb f_fd, FL_LEGACY_COMMON_ARGS,
+                                                   int len_UnconstrainedSolver, int len_Method);
 
 void nonlinearoptimization_mp_steepestdescent_(fl_f_cb f, fl_fd_cb fd, double *x, const int *dim, fl_f_fd_cb f_fd,
                                                FL_LEGACY_COMMON_ARGS);

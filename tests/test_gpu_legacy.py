@@ -186,3 +186,37 @@ def test_fortran_use_fortranlibrary_smoke():
     assert len(vals) == 10, out.stdout
     for k, v in vals.items():
         assert v < (0.2 if k == "SD" else 1e-3), (k, v)  # steepest descent on a quartic crawls; the rest reach ~1e-5
+
+
+C_CB = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int))
+
+
+@pytest.mark.parametrize("solver,osolver", [(b"LBFGS", O.LBFGS), (b"ConjugateGradient", O.CG)])
+def test_legacy_augmented_lagrangian_unit_sphere_like_test_cpp(solver, osolver):
+    """test/test.cpp:112-125 / test/test.f90:452-478: quartic, dim 10, constraint x.x = 1, AugmentedLagrangian with
+    host callbacks f, fd, c, cd through the mangled symbol; must equal the oracle bit for bit; |x| - 1 close to 0."""
+    FL = _fl()
+    n, m = 10, 1
+    rng = np.random.default_rng(3)
+    x0 = rng.random(n)
+    f, fd, ffd, cnt, (T, E), P = _callbacks(O.QUARTIC, n)
+    lib = O.lib()
+    dp = C.POINTER(C.c_double)
+    lib.flo_prob_c.argtypes = [dp, dp, C.c_int, C.c_int, C.c_void_p]
+    lib.flo_prob_cd.argtypes = [dp, dp, C.c_int, C.c_int, C.c_void_p]
+    c = C_CB(lambda cx, x, M, N: lib.flo_prob_c(cx, x, M[0], N[0], None))
+    cd = C_CB(lambda cdx, x, M, N: lib.flo_prob_cd(cdx, x, M[0], N[0], None))
+    x = x0.copy()
+    N_, M_ = C.c_int(n), C.c_int(m)
+    lam0 = np.zeros(m)
+    miu0 = C.c_double(1.0)
+    es, mem = C.c_int(0), C.c_int(10)
+    vals, refs = _common(precision=1e-8, c2=0.45 if osolver == O.CG else 0.9)
+    FL.__nonlinearoptimization_MOD_augmentedlagrangian(f, fd, c, cd, x.ctypes.data_as(dp), C.byref(N_), C.byref(M_), solver,
+                                                       lam0.ctypes.data_as(dp), C.byref(miu0), None, None, C.byref(es),
+                                                       C.byref(mem), b"DY", None, *refs, C.c_int(len(solver)), C.c_int(2))
+    assert abs(np.linalg.norm(x) - 1.0) < 1e-7
+    ref = O.auglag_batch(osolver, O.QUARTIC, x0, m, opts=O.defaults(precision=1e-8, c2=0.45 if osolver == O.CG else 0.9),
+                         sum_mode=O.TREE, threads=T, ept=E)
+    assert np.array_equal(x, ref["x"][0])
+    assert cnt["f"] + cnt["f_fd"] == ref["nf"][0] and cnt["fd"] + cnt["f_fd"] == ref["ng"][0]
