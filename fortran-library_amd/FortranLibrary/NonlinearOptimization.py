@@ -23,7 +23,7 @@ class Options(C.Structure):
     _fields_ = [("strong", C.c_int32), ("max_iteration", C.c_int32), ("precision", C.c_double),
                 ("min_step_length", C.c_double), ("wolfe_c1", C.c_double), ("wolfe_c2", C.c_double),
                 ("increment", C.c_double), ("memory", C.c_int32), ("cg_method", C.c_int32),
-                ("fused_f_fd", C.c_int32), ("clamp", C.c_int32)]
+                ("fused_f_fd", C.c_int32), ("clamp", C.c_int32), ("exact_step", C.c_int32)]
 
 
 _vp, _dp, _ip = C.c_void_p, C.c_void_p, C.c_void_p
@@ -66,7 +66,8 @@ def default_options(solver, **kw):
     FL.fl_default_options(C.byref(o), solver)
     ren = {"Strong": "strong", "MaxIteration": "max_iteration", "Precision": "precision",
            "MinStepLength": "min_step_length", "WolfeConst1": "wolfe_c1", "WolfeConst2": "wolfe_c2",
-           "Increment": "increment", "Memory": "memory", "f_fd": "fused_f_fd", "clamp": "clamp"}
+           "Increment": "increment", "Memory": "memory", "f_fd": "fused_f_fd", "clamp": "clamp",
+           "ExactStep": "exact_step"}
     for k, v in kw.items():
         if v is None:
             continue
@@ -152,19 +153,61 @@ def SteepestDescent(objective, x, d=None, b=None, options=None, **kw):
     return out
 
 
-def bfgs_workspace(batch, n, device):
+FL.fl_workspace_bytes_for.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(Options)]
+FL.fl_workspace_bytes_for.restype = C.c_size_t
+FL.fl_newton_raphson_batched.argtypes = FL.fl_lbfgs_batched.argtypes
+FL.fl_dposv_batched.argtypes = [C.c_int, C.c_int, _dp, _dp, _ip, _vp]
+FL.fl_dpotri_batched.argtypes = [C.c_int, C.c_int, _dp, _dp, _ip, _vp]
+NEWTON_ = 4
+
+
+def bfgs_workspace(batch, n, device, options=None, solver=BFGS_):
     import torch
-    nbytes = FL.fl_workspace_bytes(BFGS_, batch, n, 0)
+    o = options if options is not None else default_options(solver, ExactStep=0)
+    nbytes = FL.fl_workspace_bytes_for(solver, batch, n, C.byref(o))
     return torch.empty(max(nbytes // 8, 1), dtype=torch.float64, device=device)
 
 
+def NewtonRaphson(objective, x, d=None, b=None, workspace_=None, options=None, **kw):
+    """Batched Newton-Raphson with the objective's analytic Hessian (reference: NO.f90:1026-1271, fdd present)."""
+    o = options if options is not None else default_options(NEWTON_, **kw)
+    B, n, out = _prep(x, d, b)
+    ws = workspace_ if workspace_ is not None else bfgs_workspace(B, n, x.device, o, NEWTON_)
+    _check(FL.fl_newton_raphson_batched(objective, B, n, _ptr(x), _ptr(d), _ptr(b), C.byref(o), _ptr(ws),
+                                        ws.numel() * 8, _ptr(out["f"]), _ptr(out["gg"]), _ptr(out["iters"]),
+                                        _ptr(out["status"]), _ptr(out["nf"]), _ptr(out["ng"]), _stream()),
+           "fl_newton_raphson_batched")
+    out["workspace"] = ws
+    return out
+
+
+def dposv(A, b):
+    """My_dposv for a batch: A [batch, n, ld] column-major SPD (overwritten by its Cholesky factor),
+    b [batch, n] -> solution.  Returns info [batch] (0 = solved)."""
+    import torch
+    B, n = b.shape
+    info = torch.empty(B, dtype=torch.int32, device=b.device)
+    _check(FL.fl_dposv_batched(B, n, _ptr(A), _ptr(b), _ptr(info), _stream()), "fl_dposv_batched")
+    return info
+
+
+def dpotri(A):
+    """My_dpotri + syL2U for a batch: A [batch, n, ld] column-major SPD -> A^{-1} (both triangles)."""
+    import torch
+    B, n = A.shape[0], A.shape[1]
+    work = torch.empty_like(A)
+    info = torch.empty(B, dtype=torch.int32, device=A.device)
+    _check(FL.fl_dpotri_batched(B, n, _ptr(A), _ptr(work), _ptr(info), _stream()), "fl_dpotri_batched")
+    return info
+
+
 def BFGS(objective, x, d=None, b=None, workspace_=None, options=None, **kw):
-    """Batched dense BFGS, the reference's ExactStep<=0 path (subroutine BFGS, NO.f90:632-1022)."""
-    if kw.pop("ExactStep", 0) > 0:
-        raise NotImplementedError("exact-Hessian refresh (ExactStep > 0) is not on the device path yet")
+    """Batched dense BFGS (subroutine BFGS, NO.f90:632-1022).  ExactStep (default 20 like the reference):
+    every ExactStep iterations the exact inverse Hessian of the built-in objective replaces the
+    quasi-Newton matrix (the reference's fdd branch); ExactStep <= 0: rank-2 updates only."""
     o = options if options is not None else default_options(BFGS_, **kw)
     B, n, out = _prep(x, d, b)
-    ws = workspace_ if workspace_ is not None else bfgs_workspace(B, n, x.device)
+    ws = workspace_ if workspace_ is not None else bfgs_workspace(B, n, x.device, o)
     _check(FL.fl_bfgs_batched(objective, B, n, _ptr(x), _ptr(d), _ptr(b), C.byref(o), _ptr(ws), ws.numel() * 8,
                               _ptr(out["f"]), _ptr(out["gg"]), _ptr(out["iters"]), _ptr(out["status"]),
                               _ptr(out["nf"]), _ptr(out["ng"]), _stream()), "fl_bfgs_batched")

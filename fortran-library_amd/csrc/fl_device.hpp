@@ -28,6 +28,7 @@ namespace fl {
 
 struct SolveArgs {
     int n, batch, mem, maxit, strong, fused, cg_method;
+    int exact_step; // BFGS ExactStep (NO.f90:630): > 0 = exact inverse Hessian every exact_step iterations
     double tol, minstep, c1, c2, incr;
     double *x;
     const double *d, *b;
@@ -134,6 +135,13 @@ template <int NW, int EPT> struct Objective<FL_OBJ_QUARTIC, NW, EPT> { // test/t
         }
     }
     __device__ __forceinline__ static double combine(double s0, double) { return s0; }
+    // column j of f''(x) for the thread's rows: diag(12 x^2) (test/test.f90:665-675)
+    __device__ __forceinline__ void hess_column(int j, const double (&x)[EPT], int, const double *, double (&h)[EPT])
+    {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k)
+            h[k] = (Geo<NW, EPT>::e0(k >> 1) + (k & 1) == j) ? 12.0 * x[k] * x[k] : 0.0;
+    }
 };
 
 template <int NW, int EPT> struct Objective<FL_OBJ_DIAGQUAD, NW, EPT> { // f=0.5*sum(d*x*x)-sum(b*x), g=d*x-b
@@ -157,6 +165,11 @@ template <int NW, int EPT> struct Objective<FL_OBJ_DIAGQUAD, NW, EPT> { // f=0.5
         }
     }
     __device__ __forceinline__ static double combine(double s0, double s1) { return 0.5 * s0 - s1; }
+    __device__ __forceinline__ void hess_column(int j, const double (&)[EPT], int, const double *, double (&h)[EPT])
+    {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) h[k] = (Geo<NW, EPT>::e0(k >> 1) + (k & 1) == j) ? d[k] : 0.0;
+    }
 };
 
 template <int NW, int EPT> struct Objective<FL_OBJ_ROSENBROCK, NW, EPT> {
@@ -214,6 +227,28 @@ template <int NW, int EPT> struct Objective<FL_OBJ_ROSENBROCK, NW, EPT> {
         }
     }
     __device__ __forceinline__ static double combine(double s0, double) { return s0; }
+    // column j of the tridiagonal Hessian for the thread's rows; xs = the LDS image of x left by eval()
+    //   H(i,i) = [200 if i>=1] + (1200 x_i^2 - 400 x_{i+1} + 2 if i<=n-2),  H(i,i+1) = H(i+1,i) = -400 x_i
+    __device__ __forceinline__ void hess_column(int j, const double (&x)[EPT], int n, const double *xs,
+                                                double (&h)[EPT])
+    {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int i = G::e0(k >> 1) + (k & 1);
+            double v = 0.0;
+            if (i < n) {
+                if (i == j) {
+                    if (i >= 1) v = 200.0;
+                    if (i <= n - 2) v = v + (1200.0 * x[k] * x[k] - 400.0 * xs[2 + i] + 2.0);
+                } else if (i == j - 1) {
+                    v = -400.0 * x[k];
+                } else if (i == j + 1) {
+                    v = -400.0 * xs[i]; // x[i-1]
+                }
+            }
+            h[k] = v;
+        }
+    }
 };
 
 // objective evaluated by the caller (reverse communication, fl_rci.hip): nothing compiled in
@@ -226,10 +261,19 @@ template <int NW, int EPT> struct Objective<FL_OBJ_EXTERNAL, NW, EPT> {
         s0 = s1 = 0.0;
     }
     __device__ __forceinline__ static double combine(double s0, double) { return s0; }
+    __device__ __forceinline__ void hess_column(int, const double (&)[EPT], int, const double *, double (&h)[EPT])
+    {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) h[k] = 0.0; // no Hessian by reverse communication (exact_step <= 0 only)
+    }
 };
 
+} // namespace fl
+#include "fl_dense.hpp"
+namespace fl {
+
 // ------------------------------------------------------------ the solver machine
-// METHOD: FL_SOLVER_SD | FL_SOLVER_CG | FL_SOLVER_LBFGS | FL_SOLVER_BFGS.
+// METHOD: FL_SOLVER_SD | FL_SOLVER_CG | FL_SOLVER_LBFGS | FL_SOLVER_BFGS | FL_SOLVER_NEWTON.
 // AUG = 1 wraps the objective in the augmented Lagrangian with aug_m block-sphere
 // constraints c_j = sum_{i in block j} x_i^2 - 1 (blocks of n/aug_m) and runs the
 // reference's outer loop (NO.f90:2150-2185) around the inner solver.
@@ -238,7 +282,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
     using Obj = Objective<OBJ, NW, EPT>;
     static constexpr int NPAD = G::NPAD;
     static constexpr int BF_UNROLL = 4;
-    static constexpr bool NEEDS_G0 = (METHOD != FL_SOLVER_SD);
+    static constexpr bool NEEDS_G0 = (METHOD != FL_SOLVER_SD && METHOD != FL_SOLVER_NEWTON);
     // LDS carve (doubles)
     static constexpr int L_RED = 0;                              // [2][NVMAX][NW]
     static constexpr int L_RHO = L_RED + 2 * Reducer<NW>::NVMAX * NW;
@@ -250,7 +294,9 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
     // BFGS: s, q, g broadcast arrays; the first one doubles as the g_old parking slot (the
     // broadcast arrays are only live inside direction_bfgs, g_old only outside it)
     static constexpr int L_BF = L_G0 + ((NEEDS_G0 && METHOD != FL_SOLVER_BFGS) ? NPAD : 0);
-    static constexpr int LDS_TOTAL = L_BF + (METHOD == FL_SOLVER_BFGS ? 3 * NPAD : 0);
+    // Newton: one row buffer for the Cholesky kernels (BFGS reuses its broadcast arrays)
+    static constexpr int LDS_TOTAL = L_BF + (METHOD == FL_SOLVER_BFGS ? 3 * NPAD : (METHOD == FL_SOLVER_NEWTON ? NPAD : 0));
+    using DN = Dense<NW, EPT>;
 
     const SolveArgs &A;
     double *lds;
@@ -262,6 +308,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
     double fnew, gg, pp, phid, phidold, a;
     int iters, nf, ng, status, phase, pending;
     int recent, cnt;    // L-BFGS ring
+    int main_it, h_valid; // BFGS / Newton: main-loop iteration counter (iIteration), inverse Hessian initialised
     double yy_recent, rho_recent;
     LineSearch ls;
     // augmented Lagrangian
@@ -278,7 +325,10 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
     __device__ __forceinline__ double *hist_base() const
     {
         if constexpr (METHOD == FL_SOLVER_LBFGS) return A.hist + (size_t)prob * (size_t)(2 * A.mem) * NPAD;
-        if constexpr (METHOD == FL_SOLVER_BFGS) return A.hist + (size_t)prob * (size_t)n * NPAD;
+        // BFGS: H [n][NPAD]; with ExactStep > 0 also U (exact Hessian / its Cholesky factor) and W (inverse factor)
+        if constexpr (METHOD == FL_SOLVER_BFGS)
+            return A.hist + (size_t)prob * (size_t)(A.exact_step > 0 ? 3 : 1) * (size_t)n * NPAD;
+        if constexpr (METHOD == FL_SOLVER_NEWTON) return A.hist + (size_t)prob * (size_t)n * NPAD;
         return nullptr;
     }
 
@@ -293,6 +343,8 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
         status = FL_STATUS_CONVERGED;
         recent = -1;
         cnt = 0;
+        main_it = 0;
+        h_valid = 0;
         yy_recent = rho_recent = 0.0;
         fnew = gg = pp = phid = phidold = a = 0.0;
         outer_it = 0;
@@ -411,16 +463,27 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
 
     __device__ __forceinline__ int begin_linesearch()
     {
-#pragma unroll
-        for (int k = 0; k < EPT; ++k) x0[k] = x[k]; // xold=x (doubles as the line search's x0)
-        if constexpr (NEEDS_G0) store_pad<NW, EPT>(lds + L_G0, g); // fdold=fdnew, parked in LDS
-        phidold = phid;
         // the *_fdwithf searchers only in main loops with f_fd present; the first search of L-BFGS / BFGS
         // and L-BFGS' pre-iterations never use f_fd (NO.f90:448-460, 486-498, 689-701)
         int fused = A.fused;
         if constexpr (AUG) fused = 1; // AugmentedLagrangian always passes f_fd=L_Ld (NO.f90:2153, 2161)
         if constexpr (METHOD == FL_SOLVER_LBFGS) fused = fused && (iters >= A.mem);
-        if constexpr (METHOD == FL_SOLVER_BFGS) fused = fused && (iters >= 1);
+        if constexpr (METHOD == FL_SOLVER_BFGS || METHOD == FL_SOLVER_NEWTON) {
+            // main loop `do iIteration=1,maxit` (NO.f90:717-929, 1077-1214); BFGS' first step precedes it
+            const bool in_main = (METHOD == FL_SOLVER_NEWTON) || h_valid;
+            if (in_main) {
+                if (main_it >= A.maxit) {
+                    status = FL_STATUS_MAXIT;
+                    return inner_finished();
+                }
+                ++main_it;
+            }
+            fused = fused && in_main;
+        }
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) x0[k] = x[k]; // xold=x (doubles as the line search's x0)
+        if constexpr (NEEDS_G0) store_pad<NW, EPT>(lds + L_G0, g); // fdold=fdnew, parked in LDS
+        phidold = phid;
         const int strong = (METHOD == FL_SOLVER_CG && A.cg_method == FL_CG_PR) ? 1 : A.strong;
         phase = PH_LS;
         const int rq = __builtin_amdgcn_readfirstlane(ls.begin(strong, fused, A.c1, A.c2, A.incr, a, fnew, phid));
@@ -433,6 +496,17 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
     {
         fnew = f;
         gg = gg0;
+        if constexpr (METHOD == FL_SOLVER_NEWTON) { // NO.f90:1064-1076: no gradient test when the Hessian is SPD
+            status = FL_STATUS_MAXIT;
+            if (newton_direction(true)) return begin_linesearch();
+        }
+        if constexpr (METHOD == FL_SOLVER_BFGS) { // NO.f90:674-682: exact inverse Hessian first, if asked for
+            if (A.exact_step > 0 && bfgs_exact_refresh()) {
+                h_valid = 1;
+                status = FL_STATUS_MAXIT;
+                return begin_linesearch();
+            }
+        }
 #pragma unroll
         for (int k = 0; k < EPT; ++k) p[k] = -g[k];
         phid = -gg; // p=-fdnew; phidnew=-dot_product(fdnew,fdnew)
@@ -446,10 +520,87 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
     }
     __device__ __forceinline__ int max_linesearches() const
     {
-        // L-BFGS: 1 + (mem-1) pre-iterations + maxit; BFGS (ExactStep<=0): first step + maxit; SD/CG: maxit
+        // L-BFGS: 1 + (mem-1) pre-iterations + maxit; SD/CG: maxit; BFGS / Newton count main-loop
+        // iterations in begin_linesearch (main_it)
         if constexpr (METHOD == FL_SOLVER_LBFGS) return A.mem + A.maxit;
-        if constexpr (METHOD == FL_SOLVER_BFGS) return 1 + A.maxit;
+        if constexpr (METHOD == FL_SOLVER_BFGS || METHOD == FL_SOLVER_NEWTON) return 0x7fffffff;
         return A.maxit;
+    }
+
+    // ---- dense directions (analytic Hessian of the built-in objective = the reference's fdd branch)
+    __device__ __forceinline__ void fill_hessian(double *Hm)
+    {
+        for (int j = 0; j < n; ++j) {
+            double h[EPT];
+            obj.hess_column(j, x, n, lds + L_XS, h);
+            store_pad<NW, EPT>(Hm + (size_t)j * NPAD, h);
+        }
+        __syncthreads();
+    }
+    // p = -matmul(H, g): thread i sums H(i,j) g_j over j in order; gbuf = LDS [NPAD]
+    __device__ __forceinline__ void neg_matvec(const double *Hm, double *gbuf)
+    {
+        __syncthreads();
+        store_pad<NW, EPT>(gbuf, g);
+        __syncthreads();
+        double acc[EPT];
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) acc[k] = 0.0;
+        for (int j = 0; j < n; j += BF_UNROLL) {
+            double h[BF_UNROLL][EPT];
+#pragma unroll
+            for (int u = 0; u < BF_UNROLL; ++u)
+                if (j + u < n) load_pad<NW, EPT>(Hm + (size_t)(j + u) * NPAD, h[u]);
+#pragma unroll
+            for (int u = 0; u < BF_UNROLL; ++u)
+                if (j + u < n) {
+                    const double gj = gbuf[j + u];
+#pragma unroll
+                    for (int k = 0; k < EPT; ++k) acc[k] = acc[k] + h[u][k] * gj;
+                }
+        }
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) p[k] = -acc[k];
+    }
+    __device__ __forceinline__ void direction_scalars() // phidnew=dot_product(fdnew,p); a=1d0
+    {
+        double q[2] = {dot_part<EPT>(g, p), dot_part<EPT>(p, p)};
+        R.run(q);
+        phid = uni(q[0]);
+        pp = uni(q[1]);
+        a = 1.0;
+    }
+    // NewtonRaphson: p=-fdnew; info=fdd(Hessian,x,dim); call My_dposv(Hessian,p,dim,info) (NO.f90:1065-1067, 1232)
+    __device__ __forceinline__ bool newton_direction(bool initial)
+    {
+        double *Hm = hist_base();
+        fill_hessian(Hm);
+        const int info = DN::cholesky(Hm, n, lds + L_BF, lds + L_CX);
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) p[k] = -g[k];
+        if (info == 0) {
+            DN::solve(Hm, n, p, R, lds + L_CX);
+            direction_scalars();
+            return true;
+        }
+        if (!initial) { // Hessian is not positive definite, use steepest descent direction (NO.f90:1235-1236)
+            phid = -gg;
+            pp = gg;
+            a = a * phidold / phid;
+        }
+        return false;
+    }
+    // BFGS: i=fdd(U,x,dim); call My_dpotri(U,dim,i); sycp(H,U); syL2U(H); p=-matmul(H,fdnew) (NO.f90:951-954)
+    __device__ __forceinline__ bool bfgs_exact_refresh()
+    {
+        double *Hm = hist_base(), *U = Hm + (size_t)n * NPAD, *W = U + (size_t)n * NPAD;
+        fill_hessian(U);
+        if (DN::cholesky(U, n, lds + L_BF, lds + L_CX) != 0) return false;
+        DN::inverse_factor(U, W, n, lds + L_BF);
+        DN::wtw(W, Hm, n, lds + L_BF);
+        neg_matvec(Hm, lds + L_BF + 2 * NPAD);
+        direction_scalars();
+        return true;
     }
 
     // the line search returned: convergence tests on the new gradient, then the new direction
@@ -482,8 +633,15 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
             direction_cg(g0);
         } else if constexpr (METHOD == FL_SOLVER_LBFGS) {
             direction_lbfgs(g0);
+        } else if constexpr (METHOD == FL_SOLVER_NEWTON) {
+            newton_direction(false);
         } else {
-            direction_bfgs(g0);
+            // After(): every ExactStep-th main-loop iteration try the exact inverse Hessian (i=mod(iIteration,freq),
+            // NO.f90:949-956); otherwise, or if it is not positive definite, the rank-2 update (957-963)
+            bool refreshed = false;
+            if (A.exact_step > 0 && h_valid && main_it % A.exact_step == 0) refreshed = bfgs_exact_refresh();
+            if (!refreshed) direction_bfgs(g0);
+            h_valid = 1;
         }
         phid = uni(phid);
         pp = uni(pp);
@@ -661,7 +819,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
     {
         double *H = hist_base();
         double *bs = lds + L_BF, *bq = bs + NPAD, *bg = bq + NPAD;
-        const bool first = (iters == 1);
+        const bool first = !h_valid; // first quasi-Newton matrix from H = a I (NO.f90:711-715)
         double sv[EPT], yv[EPT], q[EPT];
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {
@@ -776,6 +934,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
             int *iq = reinterpret_cast<int *>(sc + 32);
             *iq++ = iters; *iq++ = nf; *iq++ = ng; *iq++ = status; *iq++ = phase; *iq++ = pending;
             *iq++ = recent; *iq++ = cnt; *iq++ = ls.st; *iq++ = ls.zret; *iq++ = ls.fused;
+            *iq++ = main_it; *iq++ = h_valid;
         }
     }
     __device__ __forceinline__ void load(const double *sc, const double *vec, const double *rho, double &fv_c,
@@ -802,6 +961,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
         const int *iq = reinterpret_cast<const int *>(sc + 32);
         iters = *iq++; nf = *iq++; ng = *iq++; status = *iq++; phase = *iq++; pending = *iq++;
         recent = *iq++; cnt = *iq++; ls.st = *iq++; ls.zret = *iq++; ls.fused = *iq++;
+        main_it = *iq++; h_valid = *iq++;
     }
 
     // ---------------------------------------------------------------- outputs

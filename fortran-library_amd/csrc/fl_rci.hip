@@ -153,6 +153,7 @@ int fl_rci_create(fl_rci **out, int solver, int batch, int n, const fl_options *
         A.c2 = c2 < 1.0 - 1e-15 ? c2 : 1.0 - 1e-15;
     }
     A.incr = opt->increment;
+    A.exact_step = 0; // no Hessian travels by reverse communication: quasi-Newton updates only
     A.miu0 = 1.0;
     A.precision = opt->precision;
     const size_t npad = (size_t)threads * ept, B = (size_t)batch;

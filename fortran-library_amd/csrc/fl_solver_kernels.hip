@@ -74,6 +74,7 @@ template <int NW, int EPT, int OBJ> static hipError_t launch_m(int method, int a
     case FL_SOLVER_SD: return launch_k<NW, EPT, OBJ, FL_SOLVER_SD, 0>(A, st);
     case FL_SOLVER_CG: return launch_k<NW, EPT, OBJ, FL_SOLVER_CG, 0>(A, st);
     case FL_SOLVER_BFGS: return launch_k<NW, EPT, OBJ, FL_SOLVER_BFGS, 0>(A, st);
+    case FL_SOLVER_NEWTON: return launch_k<NW, EPT, OBJ, FL_SOLVER_NEWTON, 0>(A, st);
     default: return launch_k<NW, EPT, OBJ, FL_SOLVER_LBFGS, 0>(A, st);
     }
 }
@@ -126,9 +127,10 @@ static int solve(int method, int objective, int batch, int n, double *x, const d
     A.batch = batch;
     A.mem = opt->memory > 1 ? opt->memory : 1; // mem=max(1,Memory)
     if (method == FL_SOLVER_LBFGS && A.mem > FL_MAX_MEMORY) return FL_ERR_UNSUPPORTED_SIZE;
-    if (method == FL_SOLVER_LBFGS || method == FL_SOLVER_BFGS) {
-        if (!ws || ws_bytes < fl_workspace_bytes(method, batch, n, A.mem)) return FL_ERR_WORKSPACE;
+    if (method == FL_SOLVER_LBFGS || method == FL_SOLVER_BFGS || method == FL_SOLVER_NEWTON) {
+        if (!ws || ws_bytes < fl_workspace_bytes_for(method, batch, n, opt)) return FL_ERR_WORKSPACE;
     }
+    A.exact_step = (method == FL_SOLVER_BFGS) ? opt->exact_step : 0;
     A.maxit = opt->max_iteration;
     A.strong = opt->strong != 0;
     A.fused = opt->fused_f_fd != 0;
@@ -196,6 +198,24 @@ void fl_default_options(fl_options *o, int solver)
     o->cg_method = FL_CG_DY;
     o->fused_f_fd = 0;
     o->clamp = 1;
+    o->exact_step = 20; // NO.f90:652-653
+}
+
+size_t fl_workspace_bytes_for(int solver, int batch, int n, const fl_options *opt)
+{
+    if (!opt) return 0;
+    if (solver == FL_SOLVER_BFGS) return fl_workspace_bytes(solver, batch, n, 0) * (opt->exact_step > 0 ? 3 : 1);
+    if (solver == FL_SOLVER_NEWTON) return fl_workspace_bytes(FL_SOLVER_BFGS, batch, n, 0);
+    return fl_workspace_bytes(solver, batch, n, opt->memory);
+}
+
+int fl_newton_raphson_batched(int objective, int batch, int n, double *x_dev, const double *d_dev,
+                              const double *b_dev, const fl_options *opt, void *workspace_dev,
+                              size_t workspace_bytes, double *f_dev, double *gg_dev, int32_t *iters_dev,
+                              int32_t *status_dev, int32_t *nf_dev, int32_t *ng_dev, void *stream)
+{
+    return fl::solve(FL_SOLVER_NEWTON, objective, batch, n, x_dev, d_dev, b_dev, opt, workspace_dev, workspace_bytes,
+                     f_dev, gg_dev, iters_dev, status_dev, nf_dev, ng_dev, nullptr, stream);
 }
 
 int fl_reduction_geometry(int n, int *threads, int *ept)

@@ -28,7 +28,7 @@ module NonlinearOptimization
     type,bind(C)::fl_options!include/fl_nlopt.h: struct fl_options
         integer(c_int32_t)::strong,max_iteration
         real(c_double)::precision,min_step_length,wolfe_c1,wolfe_c2,increment
-        integer(c_int32_t)::memory,cg_method,fused_f_fd,clamp
+        integer(c_int32_t)::memory,cg_method,fused_f_fd,clamp,exact_step
     end type fl_options
 
     interface

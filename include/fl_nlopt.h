@@ -75,12 +75,17 @@ typedef struct fl_options {
                              /*     *_fdwithf line searchers, NO.f90:512-527); default 0          */
     int32_t clamp;           /* 1 = apply the fail-safe clamps on c1,c2 (NO.f90:83-86; default),   */
                              /* 0 = take them verbatim (ConjugateGradient_basic, NO.f90:2249)     */
+    int32_t exact_step;      /* BFGS ExactStep: every how many steps the exact inverse Hessian is  */
+                             /* recomputed (NO.f90:630-631, default 20; <= 0 never).  The batched  */
+                             /* solvers use the built-in objective's analytic Hessian (the fdd     */
+                             /* branch, NO.f90:675, 951); reverse communication runs <= 0 only     */
 } fl_options;
 
 #define FL_SOLVER_SD 0
 #define FL_SOLVER_CG 1
 #define FL_SOLVER_LBFGS 2
 #define FL_SOLVER_BFGS 3
+#define FL_SOLVER_NEWTON 4 /* NewtonRaphson with analytic Hessian, NO.f90:1026-1271 */
 
 int fl_version(void);
 void fl_default_options(fl_options *opt, int solver);
@@ -96,6 +101,9 @@ int fl_reduction_geometry(int n, int *threads, int *ept);
  * [batch][2*memory][padded n] fp64; FL_SOLVER_BFGS -- the inverse Hessians [batch][n][padded n];
  * 0 for SD / CG. */
 size_t fl_workspace_bytes(int solver, int batch, int n, int memory);
+/* the same from an option block: BFGS with exact_step > 0 needs three matrices per problem (inverse
+ * Hessian, Hessian / Cholesky factor, inverse factor), FL_SOLVER_NEWTON one */
+size_t fl_workspace_bytes_for(int solver, int batch, int n, const fl_options *opt);
 
 /* Batched solvers.  x_dev [batch][n] in/out (initial guess -> minimiser);
  * d_dev/b_dev [batch][n] objective data (FL_OBJ_DIAGQUAD only, else NULL);
@@ -128,6 +136,25 @@ int fl_steepest_descent_batched(int objective, int batch, int n, double *x_dev, 
 int fl_bfgs_batched(int objective, int batch, int n, double *x_dev, const double *d_dev, const double *b_dev,
                     const fl_options *opt, void *workspace_dev, size_t workspace_bytes, double *f_dev, double *gg_dev,
                     int32_t *iters_dev, int32_t *status_dev, int32_t *nf_dev, int32_t *ng_dev, void *stream);
+
+/* NewtonRaphson with the built-in objective's analytic Hessian (subroutine NewtonRaphson with fdd present,
+ * NO.f90:1026-1271; C++ binding cpp/NonlinearOptimization.hpp:344-358): p = -H^{-1} g by Cholesky solve
+ * (My_dposv, LinearAlgebra.f90:719-730), steepest-descent fallback when H is not positive definite
+ * (NO.f90:1068-1075, 1233-1237).  workspace: fl_workspace_bytes_for(FL_SOLVER_NEWTON, ...). */
+int fl_newton_raphson_batched(int objective, int batch, int n, double *x_dev, const double *d_dev,
+                              const double *b_dev, const fl_options *opt, void *workspace_dev,
+                              size_t workspace_bytes, double *f_dev, double *gg_dev, int32_t *iters_dev,
+                              int32_t *status_dev, int32_t *nf_dev, int32_t *ng_dev, void *stream);
+
+/* LinearAlgebra primitives of the path for a batch of SPD matrices (column-major [batch][n][ld], ld as
+ * fl_reduction_geometry's threads*ept, lower triangle referenced):
+ *   fl_dposv_batched  <- My_dposv  LinearAlgebra.f90:719-730: A <- Cholesky factor, b [batch][n] <- A^{-1} b
+ *   fl_dpotri_batched <- My_dpotri LinearAlgebra.f90:798-812 + dsyL2U 260-265: A <- A^{-1} (both triangles);
+ *                        work_dev: one more [batch][n][ld] buffer
+ * info_dev[batch]: 0 or the index of the first non-positive pivot (then b / A are left as the reference leaves
+ * them: b untouched, A partially factorised). */
+int fl_dposv_batched(int batch, int n, double *A_dev, double *b_dev, int32_t *info_dev, void *stream);
+int fl_dpotri_batched(int batch, int n, double *A_dev, double *work_dev, int32_t *info_dev, void *stream);
 
 /* The BFGS inverse-Hessian update AS THE REFERENCE WRITES IT: U = I - rho y s^T, rho = 1/(y.s),
  * H <- matmul(transpose(U), matmul(H, U)) + rho s s^T  (NO.f90:958-962; LinearAlgebra.f90:105-114

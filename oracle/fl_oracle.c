@@ -665,20 +665,67 @@ int flo_dpotri_lower(double *A, int n)
             A_(i, j) = v / ajj;
         }
     }
-    for (int j = 0; j < n; ++j) { /* inv(L), lower, in place */
-        A_(j, j) = 1.0 / A_(j, j);
+    /* W = inv(L) by rows: W(j,:) = (e_j - sum_{k<j} L(j,k) W(k,:)) / L(j,j); then A^{-1} = W^T W.
+     * Every sum runs over k in ascending order (what the HIP routines of fl_dense.hpp compute, so the
+     * two agree bit for bit); both triangles are filled, which makes the reference's syL2U a no-op. */
+    {
+        double *W = (double *)calloc((size_t)n * n, sizeof(double)); /* W[j*n + c] = W(j,c) */
+        for (int j = 0; j < n; ++j) {
+            for (int c = 0; c < n; ++c) {
+                double v = (c == j) ? 1.0 : 0.0;
+                for (int k = 0; k < j; ++k) v = v - A_(j, k) * W[(size_t)k * n + c];
+                W[(size_t)j * n + c] = v / A_(j, j);
+            }
+        }
+        for (int b = 0; b < n; ++b)
+            for (int a = 0; a < n; ++a) {
+                double v = 0.0;
+                for (int k = 0; k < n; ++k) v = v + W[(size_t)k * n + a] * W[(size_t)k * n + b];
+                A_(a, b) = v;
+            }
+        free(W);
+    }
+#undef A_
+    return 0;
+}
+
+/* My_dposv, LA.f90:719-730: dposv('L'): Cholesky factor in A (lower), b <- A^{-1} b; b untouched if it
+ * fails.  Forward substitution column-oriented (dtrsv 'L','N'); backward x_j = (z_j - sum_{i>j} L(i,j) x_i)
+ * / L(j,j) with the sum taken top-down in FLO_SUM_SEQ (reference BLAS order is bottom-up: same value to
+ * rounding) and in the kernels' reduction order in FLO_SUM_TREE. */
+int flo_dposv_lower(double *A, double *b, int n)
+{
+#define A_(i, j) A[(size_t)(j) * n + (i)]
+    for (int j = 0; j < n; ++j) {
+        double ajj = A_(j, j);
+        for (int k = 0; k < j; ++k) ajj = ajj - A_(j, k) * A_(j, k);
+        if (!(ajj > 0.0)) return j + 1;
+        ajj = sqrt(ajj);
+        A_(j, j) = ajj;
         for (int i = j + 1; i < n; ++i) {
-            double v = 0.0;
-            for (int k = j; k < i; ++k) v = v + A_(i, k) * A_(k, j);
-            A_(i, j) = -v / A_(i, i);
+            double v = A_(i, j);
+            for (int k = 0; k < j; ++k) v = v - A_(i, k) * A_(j, k);
+            A_(i, j) = v / ajj;
         }
     }
-    for (int j = 0; j < n; ++j) /* inv(L)^T inv(L), lower */
-        for (int i = j; i < n; ++i) {
-            double v = 0.0;
-            for (int k = i; k < n; ++k) v = v + A_(k, i) * A_(k, j);
-            A_(i, j) = v;
+    for (int j = 0; j < n; ++j) {
+        const double q = b[j] / A_(j, j);
+        b[j] = q;
+        for (int i = j + 1; i < n; ++i) b[i] = b[i] - q * A_(i, j);
+    }
+    double *t = (double *)calloc((size_t)n, sizeof(double));
+    for (int j = n - 1; j >= 0; --j) {
+        for (int i = 0; i < n; ++i) t[i] = (i > j) ? A_(i, j) * b[i] : 0.0;
+        double s;
+        if (g_mode == FLO_SUM_TREE)
+            s = flo_tree_sum(n, t);
+        else {
+            s = 0.0;
+            for (int i = 0; i < n; ++i) s = s + t[i];
         }
+        b[j] = (b[j] - s) / A_(j, j);
+    }
+    free(t);
 #undef A_
     return 0;
 }
@@ -875,6 +922,63 @@ void flo_bfgs(flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, flo_fdd_t fdd, double *x, 
             neg_matvec(n, H, g, p);
             phidnew = flo_dot(n, g, p);
             a = 1.0;
+        }
+    }
+out:
+    free(p);
+}
+
+/* NewtonRaphson with analytic Hessian (fdd present), NO.f90:1026-1271; After() 1216-1238 */
+void flo_newton(flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, flo_fdd_t fdd, double *x, int n, const flo_opts *o, void *ctx,
+                flo_stats *st)
+{
+    double tol = o->precision * o->precision, minstep = o->minstep * o->minstep, c1, c2;
+    double a = 0.0, fnew, phidnew, phidold;
+    size_t N = (size_t)n;
+    double *p = (double *)malloc(sizeof(double) * (2 * N + N * N)), *g = p + N, *H = g + N;
+    int info;
+    clamp_c(o, &c1, &c2);
+    st_zero(st);
+    initial_eval(f, fd, f_fd, &fnew, g, x, n, ctx, st);
+    st->f = fnew;
+    st->gg = flo_dot(n, g, g);
+    fdd(H, x, n, ctx);
+    for (int i = 0; i < n; ++i) p[i] = -g[i];
+    info = flo_dposv_lower(H, p, n);
+    if (info == 0) {
+        phidnew = flo_dot(n, g, p);
+        a = 1.0;
+    } else { /* Hessian is not positive definite, use steepest descent direction */
+        for (int i = 0; i < n; ++i) p[i] = -g[i];
+        phidnew = -flo_dot(n, g, g);
+        if (-phidnew < tol) goto out;
+        a = (fnew == 0.0) ? 1.0 : fabs(fnew) / sqrt(-phidnew);
+    }
+    st->status = FLO_MAXIT;
+    for (int it = 1; it <= o->maxit; ++it) {
+        phidold = phidnew;
+        line_search(o, c1, c2, f_fd != NULL, f, fd, f_fd, x, &a, p, &fnew, phidnew, g, n, ctx, st);
+        phidnew = flo_dot(n, g, g);
+        st->f = fnew;
+        st->gg = phidnew;
+        if (phidnew < tol) {
+            st->status = FLO_CONVERGED;
+            break;
+        }
+        if (flo_dot(n, p, p) * a * a < minstep) {
+            st->status = FLO_STEP_CONVERGED;
+            break;
+        }
+        for (int i = 0; i < n; ++i) p[i] = -g[i];
+        fdd(H, x, n, ctx);
+        info = flo_dposv_lower(H, p, n);
+        if (info == 0) {
+            phidnew = flo_dot(n, g, p);
+            a = 1.0;
+        } else {
+            for (int i = 0; i < n; ++i) p[i] = -g[i];
+            phidnew = -phidnew;
+            a = a * phidold / phidnew;
         }
     }
 out:

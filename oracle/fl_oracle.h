@@ -92,6 +92,10 @@ void flo_lbfgs(flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, double *x, int n, const f
  * exact_step > 0 without fdd uses an own central difference (MKL djacobi: parity unpinned). */
 void flo_bfgs(flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, flo_fdd_t fdd, double *x, int n, const flo_opts *o,
               int update_form, void *ctx, flo_stats *st);
+/* NewtonRaphson with analytic Hessian (NO.f90:1026): Cholesky solve, steepest-descent fallback */
+void flo_newton(flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, flo_fdd_t fdd, double *x, int n, const flo_opts *o, void *ctx,
+                flo_stats *st);
+int flo_dposv_lower(double *A, double *b, int n); /* My_dposv LA.f90:719 : returns info, b untouched if it fails */
 /* AugmentedLagrangian (NO.f90:2005): solver 0 = BFGS, 1 = LBFGS, 2 = ConjugateGradient.
  * lambda[m] in/out (reference: lambda0 copy), miu0 as given. outer_iters returns the
  * number of outer iterations. */

@@ -165,6 +165,8 @@ int flo_solve_batch(int solver, int kind, int B, int n, double *x, const double 
             flo_conjugate_gradient(flo_prob_f, flo_prob_fd, ffd, xk, n, o, &P, &st);
         else if (solver == FLO_LBFGS)
             flo_lbfgs(flo_prob_f, flo_prob_fd, ffd, xk, n, o, &P, &st);
+        else if (solver == 4 /* NewtonRaphson */)
+            flo_newton(flo_prob_f, flo_prob_fd, ffd, flo_prob_fdd, xk, n, o, &P, &st);
         else
             flo_bfgs(flo_prob_f, flo_prob_fd, ffd, o->exact_step > 0 ? flo_prob_fdd : NULL, xk, n, o, bfgs_form, &P,
                      &st);

@@ -159,7 +159,8 @@ def test_rci_batched_torch_objective_equals_fused_kernel():
         assert float(((x - xs).norm(dim=1) / xs.norm(dim=1)).max()) < 1e-5
         x2 = torch.zeros(B, n, dtype=torch.float64, device=dev)
         fused = {NLO.LBFGS_: NLO.LBFGS, NLO.CG: NLO.ConjugateGradient, NLO.BFGS_: NLO.BFGS}[solver]
-        ref = fused(NLO.DIAGQUAD, x2, d, b, Precision=1e-6)
+        extra = {"ExactStep": 0} if solver == NLO.BFGS_ else {}
+        ref = fused(NLO.DIAGQUAD, x2, d, b, Precision=1e-6, **extra)
         assert torch.allclose(out["f"], ref["f"], rtol=1e-10, atol=0)
 
 

@@ -239,6 +239,7 @@ def _gpu_bfgs(kind, x0, d=None, b=None, **kw):
     x = torch.tensor(np.atleast_2d(x0), dtype=torch.float64, device=dev).contiguous()
     dd = torch.tensor(np.broadcast_to(d, x.shape).copy(), device=dev) if d is not None else None
     bb = torch.tensor(np.broadcast_to(b, x.shape).copy(), device=dev) if b is not None else None
+    kw.setdefault("ExactStep", 0)
     out = NLO.BFGS(kind, x, dd, bb, **kw)
     torch.cuda.synchronize()
     res = {k: v.cpu().numpy() for k, v in out.items() if k != "workspace"}
@@ -251,9 +252,100 @@ def _oracle_bfgs(kind, x0, d, b, form, mode, kw):
     n = np.atleast_2d(x0).shape[1]
     T, E = NLO.reduction_geometry(n)
     o = _oracle_opts(O.BFGS, kw)
-    o.exact_step = 0
+    o.exact_step = kw.get("ExactStep", 0)
     return O.solve_batch(O.BFGS, kind, x0, d=d, b=b, opts=o, use_ffd=bool(kw.get("f_fd", False)), bfgs_form=form,
                          sum_mode=mode, threads=T, ept=E)
+
+
+@pytest.mark.parametrize("kind,n,kw", [(O.ROSENBROCK, 10, {"ExactStep": 20}), (O.ROSENBROCK, 10, {"ExactStep": 5}),
+                                       (O.ROSENBROCK, 10, {"ExactStep": 3, "f_fd": True}), (O.QUARTIC, 10, {"ExactStep": 5}),
+                                       (O.DIAGQUAD, 96, {"ExactStep": 20}), (O.ROSENBROCK, 130, {"ExactStep": 4, "MaxIteration": 30}),
+                                       (O.ROSENBROCK, 300, {"ExactStep": 2, "MaxIteration": 6})])
+def test_bfgs_exact_hessian_refresh_bitexact(kind, n, kw):
+    """BFGS with ExactStep > 0 (the reference's fdd branch, NO.f90:674-682, 949-956): analytic Hessian ->
+    Cholesky inverse (My_dpotri) every ExactStep iterations, rank-2 updates in between; standard start of
+    Rosenbrock is NOT positive definite at first, which exercises the fall-back paths."""
+    rng = np.random.default_rng(n)
+    B = 3
+    if kind == O.ROSENBROCK:
+        x0 = np.full((B, n), -1.2)
+        x0[:, 1::2] = 1.0
+        x0[1:] = 1.0 + 0.1 * rng.uniform(-1, 1, (B - 1, n))
+        d = b = None
+    elif kind == O.QUARTIC:
+        x0, d, b = np.vstack([0.1 * np.arange(1, n + 1), rng.random((B - 1, n))]), None, None
+    else:
+        d, b = _quads(B, n, 10.0, 300.0, n)
+        x0 = np.zeros((B, n))
+    g = _gpu_bfgs(kind, x0, d, b, **kw)
+    o = _oracle_bfgs(kind, x0, d, b, 1, O.TREE, kw)
+    _assert_bitexact(g, o)
+
+
+@pytest.mark.parametrize("kind,n,kw", [(O.ROSENBROCK, 10, {}), (O.ROSENBROCK, 10, {"f_fd": True}), (O.ROSENBROCK, 10, {"Strong": False}),
+                                       (O.QUARTIC, 10, {}), (O.DIAGQUAD, 96, {}), (O.ROSENBROCK, 130, {}),
+                                       (O.ROSENBROCK, 257, {"MaxIteration": 8}), (O.DIAGQUAD, 600, {})])
+def test_newton_raphson_bitexact(kind, n, kw):
+    """NewtonRaphson with analytic Hessian (NO.f90:1026-1271): Cholesky solve (My_dposv) per iteration,
+    steepest-descent fallback where the Hessian is not positive definite (Rosenbrock's standard start)."""
+    NLO = _nlo()
+    rng = np.random.default_rng(n + 1)
+    B = 3
+    if kind == O.ROSENBROCK:
+        x0 = np.full((B, n), -1.2)
+        x0[:, 1::2] = 1.0
+        x0[1:] = 1.0 + 0.1 * rng.uniform(-1, 1, (B - 1, n))
+        d = b = None
+    elif kind == O.QUARTIC:
+        x0, d, b = np.vstack([0.1 * np.arange(1, n + 1), rng.random((B - 1, n))]), None, None
+    else:
+        d, b = _quads(B, n, 10.0, 300.0, n)
+        x0 = np.zeros((B, n))
+    dev = torch.device("cuda:0")
+    x = torch.tensor(x0, device=dev)
+    dd = torch.tensor(d, device=dev) if d is not None else None
+    bb = torch.tensor(b, device=dev) if b is not None else None
+    out = NLO.NewtonRaphson(kind, x, dd, bb, **kw)
+    torch.cuda.synchronize()
+    g = {k: v.cpu().numpy() for k, v in out.items() if k != "workspace"}
+    g["x"] = x.cpu().numpy()
+    T, E = NLO.reduction_geometry(n)
+    o = O.solve_batch(4, kind, x0, d=d, b=b, opts=_oracle_opts(4, kw), use_ffd=bool(kw.get("f_fd", False)),
+                      sum_mode=O.TREE, threads=T, ept=E)
+    _assert_bitexact(g, o)
+    if kind == O.DIAGQUAD:  # Newton solves a quadratic in one full step (then polishes to Precision = 1e-15)
+        assert np.all(np.linalg.norm(g["x"] - b / d, axis=1) <= 1e-12 * np.linalg.norm(b / d, axis=1))
+
+
+def test_dposv_dpotri_batched_against_numpy():
+    """LinearAlgebra primitives My_dposv / My_dpotri (+syL2U) for a batch, incl. a non-SPD matrix (info > 0)"""
+    NLO = _nlo()
+    rng = np.random.default_rng(9)
+    dev = torch.device("cuda:0")
+    for n in (5, 64, 200):
+        T, E = NLO.reduction_geometry(n)
+        ld = T * E
+        B = 4
+        M = rng.standard_normal((B, n, n))
+        A = M @ M.transpose(0, 2, 1) / n + np.eye(n)[None]
+        A[3, 2, 2] = -1.0  # not positive definite: LAPACK info = 3
+        rhs = rng.standard_normal((B, n))
+        Ap = np.zeros((B, n, ld))
+        Ap[:, :, :n] = A
+        Ad, bd = torch.tensor(Ap, device=dev), torch.tensor(rhs, device=dev)
+        info = NLO.dposv(Ad, bd).cpu().numpy()
+        assert list(info) == [0, 0, 0, 3]
+        sol = bd.cpu().numpy()
+        for k in range(3):
+            assert np.allclose(sol[k], np.linalg.solve(A[k], rhs[k]), rtol=1e-9, atol=1e-11)
+        assert np.array_equal(sol[3], rhs[3])  # b untouched when the factorisation fails
+        Ad = torch.tensor(Ap, device=dev)
+        info = NLO.dpotri(Ad).cpu().numpy()
+        assert list(info) == [0, 0, 0, 3]
+        inv = Ad.cpu().numpy()[:, :, :n]
+        for k in range(3):
+            assert np.allclose(inv[k], np.linalg.inv(A[k]), rtol=1e-8, atol=1e-10)
+            assert np.array_equal(inv[k], inv[k].T)  # both triangles, exactly symmetric
 
 
 @pytest.mark.parametrize("kind,n,kw", [(O.QUARTIC, 10, {}), (O.ROSENBROCK, 10, {}), (O.ROSENBROCK, 10, {"f_fd": True}),

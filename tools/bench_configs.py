@@ -134,7 +134,7 @@ def main():
 
         def run():
             x.zero_()
-            return NLO.BFGS(NLO.DIAGQUAD, x, d, b, workspace_=ws, Precision=1e-12, MaxIteration=K - 1)
+            return NLO.BFGS(NLO.DIAGQUAD, x, d, b, workspace_=ws, Precision=1e-12, MaxIteration=K - 1, ExactStep=0)
         out, ms = timed(run, 2)
         it = out["iters"].to(torch.int64)
         # rank-2 form: per update 8n^2 (q = H y) + 16n^2 (read H, write H'); the first update only writes 8n^2
