@@ -221,3 +221,25 @@ def test_legacy_augmented_lagrangian_unit_sphere_like_test_cpp(solver, osolver):
                          sum_mode=O.TREE, threads=T, ept=E)
     assert np.array_equal(x, ref["x"][0])
     assert cnt["f"] + cnt["f_fd"] == ref["nf"][0] and cnt["fd"] + cnt["f_fd"] == ref["ng"][0]
+
+
+def test_cpp_caller_links_and_runs_against_libFL():
+    """A C++ program that declares the mangled symbols like the reference header (C++ references, -1/0 logicals,
+    hidden string lengths) links with plain g++ against libFL.so and runs the reference test's optimiser calls."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "tests", "legacy_cpp_caller.cpp")
+    exe = os.path.join(root, "tests", "_build", "legacy_cpp_caller")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    lib = os.path.join(root, "fortran-library_amd", "lib")
+    if not os.path.exists(exe) or os.path.getmtime(src) > os.path.getmtime(exe):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", src, "-o", exe, "-L" + lib, "-lFL", "-Wl,-rpath," + lib])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, LD_LIBRARY_PATH=lib + ":" + os.environ.get("LD_LIBRARY_PATH", "")))
+    assert out.returncode == 0, out.stderr
+    assert "Mission complete" in out.stdout
+    vals = dict(line.split() for line in out.stdout.splitlines() if len(line.split()) == 2 and line[0] != "M")
+    assert len(vals) == 5
+    for k, v in vals.items():
+        assert float(v) < (0.2 if k == "SD" else 1e-3 if not k.startswith("AugLag") else 1e-7), (k, v)
