@@ -22,6 +22,7 @@
 #include "fl_reduce.hpp"
 
 #define FL_REQ_NOMOVE 8 // evaluate at the current x (do not form x0 + a p)
+#define FL_REQ_H 16     // reverse communication: the Hessian at the current x is wanted (fdd, NO.f90:37)
 #define FL_MAX_CONSTRAINTS 16
 
 namespace fl {
@@ -309,13 +310,15 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
     int iters, nf, ng, status, phase, pending;
     int recent, cnt;    // L-BFGS ring
     int main_it, h_valid; // BFGS / Newton: main-loop iteration counter (iIteration), inverse Hessian initialised
+    int hess_stage;       // reverse communication: where to resume once the caller has supplied the Hessian
+    static constexpr bool HESS_RCI = (OBJ == FL_OBJ_EXTERNAL);
     double yy_recent, rho_recent;
     LineSearch ls;
     // augmented Lagrangian
     double miu, cc;
     int outer_it, inner_iters_total;
 
-    enum { PH_INIT = 0, PH_LS = 1, PH_DONE = 2 };
+    enum { PH_INIT = 0, PH_LS = 1, PH_DONE = 2, PH_HESS = 3 };
 
     __device__ __forceinline__ Solver(const SolveArgs &A_, double *lds_)
         : A(A_), lds(lds_), prob(blockIdx.x), n(A_.n), R{lds_ + L_RED, 0}
@@ -345,6 +348,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
         cnt = 0;
         main_it = 0;
         h_valid = 0;
+        hess_stage = 0;
         yy_recent = rho_recent = 0.0;
         fnew = gg = pp = phid = phidold = a = 0.0;
         outer_it = 0;
@@ -450,6 +454,8 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
         int rq;
         if (phase == PH_INIT) {
             rq = after_init(fv, gg_new);
+        } else if (phase == PH_HESS) { // the caller has written the Hessian it was asked for
+            rq = (hess_stage == 0) ? after_init_rest() : direction_and_begin();
         } else {
             gg = gg_new;
             rq = __builtin_amdgcn_readfirstlane(ls.step(fv, pv));
@@ -496,6 +502,17 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
     {
         fnew = f;
         gg = gg0;
+        if constexpr (HESS_RCI && (METHOD == FL_SOLVER_NEWTON || METHOD == FL_SOLVER_BFGS)) {
+            if (METHOD == FL_SOLVER_NEWTON || A.exact_step > 0) { // info=fdd(H,x,dim): ask the caller (NO.f90:675, 1065)
+                phase = PH_HESS;
+                hess_stage = 0;
+                return FL_REQ_H | FL_REQ_SAME;
+            }
+        }
+        return after_init_rest();
+    }
+    __device__ __forceinline__ int after_init_rest()
+    {
         if constexpr (METHOD == FL_SOLVER_NEWTON) { // NO.f90:1064-1076: no gradient test when the Hessian is SPD
             status = FL_STATUS_MAXIT;
             if (newton_direction(true)) return begin_linesearch();
@@ -530,6 +547,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
     // ---- dense directions (analytic Hessian of the built-in objective = the reference's fdd branch)
     __device__ __forceinline__ void fill_hessian(double *Hm)
     {
+        if constexpr (HESS_RCI) return; // reverse communication: the caller has written it (FL_REQ_H)
         for (int j = 0; j < n; ++j) {
             double h[EPT];
             obj.hess_column(j, x, n, lds + L_XS, h);
@@ -621,6 +639,17 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
             status = FL_STATUS_MAXIT;
             return inner_finished();
         }
+        if constexpr (HESS_RCI && (METHOD == FL_SOLVER_NEWTON || METHOD == FL_SOLVER_BFGS)) {
+            if (METHOD == FL_SOLVER_NEWTON || (A.exact_step > 0 && h_valid && main_it % A.exact_step == 0)) {
+                phase = PH_HESS; // info=fdd(...,x,dim): the Hessian at the new x comes from the caller
+                hess_stage = 1;
+                return FL_REQ_H | FL_REQ_SAME;
+            }
+        }
+        return direction_and_begin();
+    }
+    __device__ __forceinline__ int direction_and_begin()
+    {
         double g0[EPT];
         if constexpr (NEEDS_G0) load_pad<NW, EPT>(lds + L_G0, g0);
         if constexpr (METHOD == FL_SOLVER_SD) { // NO.f90:185-186
@@ -914,6 +943,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
     {
         store_pad<NW, EPT>(vec, p);
         store_pad<NW, EPT>(vec + NPAD, x0);
+        store_pad<NW, EPT>(vec + 3 * NPAD, g);
         if constexpr (NEEDS_G0) {
             double g0[EPT];
             load_pad<NW, EPT>(lds + L_G0, g0);
@@ -934,7 +964,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
             int *iq = reinterpret_cast<int *>(sc + 32);
             *iq++ = iters; *iq++ = nf; *iq++ = ng; *iq++ = status; *iq++ = phase; *iq++ = pending;
             *iq++ = recent; *iq++ = cnt; *iq++ = ls.st; *iq++ = ls.zret; *iq++ = ls.fused;
-            *iq++ = main_it; *iq++ = h_valid;
+            *iq++ = main_it; *iq++ = h_valid; *iq++ = hess_stage;
         }
     }
     __device__ __forceinline__ void load(const double *sc, const double *vec, const double *rho, double &fv_c,
@@ -942,6 +972,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
     {
         load_pad<NW, EPT>(vec, p);
         load_pad<NW, EPT>(vec + NPAD, x0);
+        load_pad<NW, EPT>(vec + 3 * NPAD, g);
         if constexpr (NEEDS_G0) {
             double g0[EPT];
             load_pad<NW, EPT>(vec + 2 * NPAD, g0);
@@ -961,7 +992,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
         const int *iq = reinterpret_cast<const int *>(sc + 32);
         iters = *iq++; nf = *iq++; ng = *iq++; status = *iq++; phase = *iq++; pending = *iq++;
         recent = *iq++; cnt = *iq++; ls.st = *iq++; ls.zret = *iq++; ls.fused = *iq++;
-        main_it = *iq++; h_valid = *iq++;
+        main_it = *iq++; h_valid = *iq++; hess_stage = *iq++;
     }
 
     // ---------------------------------------------------------------- outputs

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(NW * 64) void rci_step_kernel(SolveArgs A, int firs
     S s(A, lds);
     const int prob = blockIdx.x, n = A.n;
     double *sc = sc_all + (size_t)prob * S::RCI_SCALARS;
-    double *vec = vec_all + (size_t)prob * 3 * S::NPAD;
+    double *vec = vec_all + (size_t)prob * 4 * S::NPAD;
     double *rho = rho_all + (size_t)prob * FL_MAX_MEMORY;
     s.init(); // x = the point the caller has just evaluated (or the initial guess)
     int rq;
@@ -86,6 +86,7 @@ template <int NW, int EPT> static void launch_rci(Rci *h, const double *f, const
     case FL_SOLVER_SD: FL_RCI(FL_SOLVER_SD); break;
     case FL_SOLVER_CG: FL_RCI(FL_SOLVER_CG); break;
     case FL_SOLVER_BFGS: FL_RCI(FL_SOLVER_BFGS); break;
+    case FL_SOLVER_NEWTON: FL_RCI(FL_SOLVER_NEWTON); break;
     default: FL_RCI(FL_SOLVER_LBFGS); break;
     }
 #undef FL_RCI
@@ -113,7 +114,7 @@ int fl_rci_destroy(fl_rci *h)
 int fl_rci_create(fl_rci **out, int solver, int batch, int n, const fl_options *opt, void *stream)
 {
     if (!out || !opt || batch <= 0 || n <= 0) return FL_ERR_INVALID_ARGUMENT;
-    if (solver < FL_SOLVER_SD || solver > FL_SOLVER_BFGS) return FL_ERR_INVALID_ARGUMENT;
+    if (solver < FL_SOLVER_SD || solver > FL_SOLVER_NEWTON) return FL_ERR_INVALID_ARGUMENT;
     if (opt->cg_method != FL_CG_DY && opt->cg_method != FL_CG_PR) return FL_ERR_INVALID_ARGUMENT;
     int threads = 0, ept = 0;
     if (fl_reduction_geometry(n, &threads, &ept) != FL_OK) return FL_ERR_UNSUPPORTED_SIZE;
@@ -153,13 +154,13 @@ int fl_rci_create(fl_rci **out, int solver, int batch, int n, const fl_options *
         A.c2 = c2 < 1.0 - 1e-15 ? c2 : 1.0 - 1e-15;
     }
     A.incr = opt->increment;
-    A.exact_step = 0; // no Hessian travels by reverse communication: quasi-Newton updates only
+    A.exact_step = (solver == FL_SOLVER_BFGS) ? opt->exact_step : 0; // > 0: the caller answers FL_REQ_H requests
     A.miu0 = 1.0;
     A.precision = opt->precision;
     const size_t npad = (size_t)threads * ept, B = (size_t)batch;
-    const size_t wsb = fl_workspace_bytes(solver, batch, n, A.mem);
+    const size_t wsb = fl_workspace_bytes_for(solver, batch, n, opt);
     bool ok = hipMalloc((void **)&r.sc, B * 48 * sizeof(double)) == hipSuccess &&
-              hipMalloc((void **)&r.vec, B * 3 * npad * sizeof(double)) == hipSuccess &&
+              hipMalloc((void **)&r.vec, B * 4 * npad * sizeof(double)) == hipSuccess &&
               hipMalloc((void **)&r.rho, B * FL_MAX_MEMORY * sizeof(double)) == hipSuccess &&
               hipMalloc((void **)&r.f_out, B * sizeof(double)) == hipSuccess &&
               hipMalloc((void **)&r.gg_out, B * sizeof(double)) == hipSuccess &&
@@ -200,6 +201,17 @@ int fl_rci_step(fl_rci *h, double *x_dev, const double *f_dev, const double *g_d
     return hipGetLastError() == hipSuccess ? FL_OK : FL_ERR_NO_DEVICE;
 }
 
+int fl_rci_hessian_buffer(fl_rci *h, double **hessian_dev, int *ld)
+{
+    if (!h || !hessian_dev || !ld) return FL_ERR_INVALID_ARGUMENT;
+    const size_t npad = (size_t)h->r.nw * 64 * h->r.ept, mat = (size_t)h->r.n * npad;
+    if (h->r.solver == FL_SOLVER_NEWTON) *hessian_dev = h->r.ws;                                  // [batch][n][ld]
+    else if (h->r.solver == FL_SOLVER_BFGS && h->r.A.exact_step > 0) *hessian_dev = h->r.ws + mat; // U of (H,U,W)
+    else return FL_ERR_INVALID_ARGUMENT;
+    *ld = (int)npad;
+    return FL_OK;
+}
+
 int fl_rci_results(fl_rci *h, double *f_dev, double *gg_dev, int32_t *iters_dev, int32_t *status_dev, int32_t *nf_dev,
                    int32_t *ng_dev)
 {
@@ -225,6 +237,7 @@ typedef int (*fdd_cb)(double *, const double *, const int &);
 // One problem, host callbacks: the machine steps on the GPU, f / f' are evaluated by the caller's
 // code on the host exactly when the reference would call them (request bits).  Returns the status.
 struct HostObjective { // the caller's code, evaluated on the host when the machine asks for it
+    std::function<void(double *, const double *, int)> fdd; // Hessian, column-major n x n (empty = absent)
     std::function<void(double &, const double *, int)> f;
     std::function<void(double *, const double *, int)> fd;
     std::function<void(double &, double *, const double *, int)> f_fd; // empty = f_fd absent
@@ -249,7 +262,7 @@ static int legacy_solve(int solver, const char *name, const HostObjective &ob, d
     }
     double *xd = nullptr, *fdv = nullptr, *gd = nullptr;
     int32_t *rqd = nullptr;
-    std::vector<double> g(n);
+    std::vector<double> g(n), hess;
     double fx = 0.0;
     int32_t rq = 0, status = FL_STATUS_MAXIT;
     bool ok = hipMalloc((void **)&xd, sizeof(double) * n) == hipSuccess &&
@@ -263,6 +276,18 @@ static int legacy_solve(int solver, const char *name, const HostObjective &ob, d
         if (rq == 0) break;
         if (!(rq & FL_REQ_SAME))
             if (hipMemcpy(x, xd, sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+        if (rq & FL_REQ_H) { // info=fdd(H,x,dim): evaluate on the host, copy into the handle's padded buffer
+            double *Hd = nullptr;
+            int ld = 0;
+            if (!ob.fdd || fl_rci_hessian_buffer(h, &Hd, &ld) != FL_OK) { ok = false; break; }
+            if (hess.empty()) hess.resize((size_t)n * n);
+            ob.fdd(hess.data(), x, n);
+            const size_t stride = (h->r.solver == FL_SOLVER_BFGS) ? 3 : 1; // batch of one: problem 0
+            (void)stride;
+            if (hipMemcpy2D(Hd, sizeof(double) * ld, hess.data(), sizeof(double) * n, sizeof(double) * n, n,
+                            hipMemcpyHostToDevice) != hipSuccess) { ok = false; break; }
+            continue;
+        }
         const bool wf = rq & FL_REQ_F, wg = rq & FL_REQ_G;
         if (wf && wg && ob.f_fd) {
             ob.f_fd(fx, g.data(), x, n); // the integer return value is ignored like the reference does (NO.f90:437)
@@ -389,15 +414,45 @@ void __nonlinearoptimization_MOD_lbfgs(f_cb f, fd_cb fd, double *x, const int *d
 void __nonlinearoptimization_MOD_bfgs(f_cb f, fd_cb fd, double *x, const int *dim, fdd_cb fdd, const int *ExactStep,
                                       ffd_cb f_fd, FL_LEGACY_COMMON)
 {
-    (void)fdd;
     fl_options o;
     legacy_options(o, FL_SOLVER_BFGS, Strong, MaxIteration, Precision, MinStepLength, WolfeConst1, WolfeConst2,
                    Increment, f_fd);
     const int freq = ExactStep ? *ExactStep : 20;
-    if (freq > 0 && warn_of(Warning))
-        std::printf(" BFGS (MI355X): exact Hessian refresh (ExactStep=%d) is not available on the device path;"
-                    " continuing with quasi-Newton updates only (ExactStep=0)\n", freq);
-    legacy_solve(FL_SOLVER_BFGS, "BFGS", host_objective(f, fd, f_fd), x, *dim, o, warn_of(Warning));
+    o.exact_step = freq;
+    HostObjective ob = host_objective(f, fd, f_fd);
+    if (freq > 0 && fdd) {
+        ob.fdd = [fdd](double *H, const double *xx, int n) { (void)fdd(H, xx, n); };
+    } else if (freq > 0) { // fdd absent: the reference differentiates numerically with MKL djacobi (NO.f90:676)
+        o.exact_step = 0;
+        if (warn_of(Warning))
+            std::printf(" BFGS (MI355X): no analytical Hessian (fdd) given and MKL djacobi is not part of this build;"
+                        " continuing with quasi-Newton updates only (ExactStep=0)\n");
+    }
+    legacy_solve(FL_SOLVER_BFGS, "BFGS", ob, x, *dim, o, warn_of(Warning));
+}
+
+// subroutine NewtonRaphson(f,fd,x,dim,fdd,f_fd,Strong,...)  NO.f90:1026 ; hpp:344-358.  fdd is required here
+// (the reference falls back to MKL djacobi without it, NO.f90:1066).
+void __nonlinearoptimization_MOD_newtonraphson(f_cb f, fd_cb fd, double *x, const int *dim, fdd_cb fdd, ffd_cb f_fd,
+                                               FL_LEGACY_COMMON)
+{
+    if (!fdd) {
+        std::printf(" Newton-Raphson (MI355X): an analytical Hessian (fdd) is required; MKL djacobi is not part of"
+                    " this build.  x is unchanged\n");
+        return;
+    }
+    fl_options o;
+    legacy_options(o, FL_SOLVER_NEWTON, Strong, MaxIteration, Precision, MinStepLength, WolfeConst1, WolfeConst2,
+                   Increment, f_fd);
+    HostObjective ob = host_objective(f, fd, f_fd);
+    ob.fdd = [fdd](double *H, const double *xx, int n) { (void)fdd(H, xx, n); };
+    legacy_solve(FL_SOLVER_NEWTON, "Newton-Raphson", ob, x, *dim, o, warn_of(Warning));
+}
+void nonlinearoptimization_mp_newtonraphson_(f_cb f, fd_cb fd, double *x, const int *dim, fdd_cb fdd, ffd_cb f_fd,
+                                             FL_LEGACY_COMMON)
+{
+    __nonlinearoptimization_MOD_newtonraphson(f, fd, x, dim, fdd, f_fd, Strong, Warning, MaxIteration, Precision,
+                                              MinStepLength, WolfeConst1, WolfeConst2, Increment);
 }
 
 // subroutine AugmentedLagrangian(f,fd,c,cd,x,N,M,UnconstrainedSolver,lambda0,miu0,fdd,cdd,ExactStep,Memory,Method,
@@ -435,6 +490,7 @@ void __nonlinearoptimization_MOD_augmentedlagrangian(f_cb f, fd_cb fd, c_cb c, c
     if (!WolfeConst2) o.wolfe_c2 = (sv == FL_SOLVER_CG) ? 0.45 : 0.9; // NO.f90:2053-2062
     if (Memory) o.memory = *Memory;
     o.fused_f_fd = 1; // the inner solver always receives f_fd=L_Ld (NO.f90:2134, 2153, 2171)
+    o.exact_step = 0; // no Ldd on the device path: quasi-Newton branch
     if (sv == FL_SOLVER_CG) {
         const int mth = cg_method_of(Method, Method ? len_method : 0);
         if (mth < 0) {

@@ -16,8 +16,8 @@
 !  BFGS              <- reference NonlinearOptimization.f90:632 (ExactStep <= 0 branch on the device)
 !New: LBFGS_batched / ConjugateGradient_batched -- batches of independent problems with
 !device-resident data and built-in objectives (include/fl_nlopt.h).
-!Not provided (out of scope, SURVEY.md section 8f): NewtonRaphson, TrustRegion (MKL RCI),
-!LagrangianMultiplier; AugmentedLagrangian is available in batched form from C / Python.
+!  NewtonRaphson     <- reference NonlinearOptimization.f90:1026 (fdd required)
+!Not provided (SURVEY.md sections 2, 8f): TrustRegion (MKL RCI), LagrangianMultiplier; AugmentedLagrangian is available in batched form from C / Python.
 module NonlinearOptimization
     use iso_c_binding
     implicit none
@@ -66,6 +66,14 @@ module NonlinearOptimization
             integer(c_int),intent(in)::dim
             type(c_ptr),value::ExactStep,Strong,Warning,MaxIteration,Precision,MinStepLength,WolfeConst1,WolfeConst2,Increment
         end subroutine flc_bfgs
+        subroutine flc_newtonraphson(f,fd,x,dim,fdd,f_fd,Strong,Warning,MaxIteration,Precision,MinStepLength,&
+        WolfeConst1,WolfeConst2,Increment) bind(C,name='__nonlinearoptimization_MOD_newtonraphson')
+            import
+            type(c_funptr),value::f,fd,fdd,f_fd
+            real(c_double)::x(*)
+            integer(c_int),intent(in)::dim
+            type(c_ptr),value::Strong,Warning,MaxIteration,Precision,MinStepLength,WolfeConst1,WolfeConst2,Increment
+        end subroutine flc_newtonraphson
         subroutine fl_default_options(opt,solver) bind(C,name='fl_default_options')
             import
             type(fl_options),intent(out)::opt
@@ -188,6 +196,29 @@ contains
         pfdd=c_null_funptr; if(present(fdd)) pfdd=c_funloc(fdd)
         call flc_bfgs(c_funloc(f),c_funloc(fd),x,dim,pfdd,pe,pf_fd,p(1),p(2),p(3),p(4),p(5),p(6),p(7),p(8))
     end subroutine BFGS
+
+    !Newton-Raphson method (reference NonlinearOptimization.f90:1026); fdd (analytical Hessian) is required here:
+    !without it the reference calls MKL djacobi, which is not part of this build
+    subroutine NewtonRaphson(f, fd, x, dim, &
+    fdd, &
+    f_fd, Strong, Warning, MaxIteration, Precision, MinStepLength, WolfeConst1, WolfeConst2, Increment)
+        external::f,fd
+        integer,intent(in)::dim
+        real*8,dimension(dim),intent(inout)::x
+        integer,external,optional::fdd,f_fd
+        logical,intent(in),optional::Strong,Warning
+        integer,intent(in),optional::MaxIteration
+        real*8,intent(in),optional::Precision,MinStepLength,WolfeConst1,WolfeConst2,Increment
+        integer(c_int32_t),target::ls(2)
+        integer(c_int),target::li(1)
+        real(c_double),target::lr(5)
+        type(c_ptr)::p(8)
+        type(c_funptr)::pf_fd,pfdd
+        call pack_common(p,ls,li,lr,Strong,Warning,MaxIteration,Precision,MinStepLength,WolfeConst1,WolfeConst2,Increment)
+        pf_fd=c_null_funptr; if(present(f_fd)) pf_fd=c_funloc(f_fd)
+        pfdd=c_null_funptr; if(present(fdd)) pfdd=c_funloc(fdd)
+        call flc_newtonraphson(c_funloc(f),c_funloc(fd),x,dim,pfdd,pf_fd,p(1),p(2),p(3),p(4),p(5),p(6),p(7),p(8))
+    end subroutine NewtonRaphson
 
     subroutine pack_common(p,ls,li,lr,Strong,Warning,MaxIteration,Precision,MinStepLength,WolfeConst1,WolfeConst2,Increment)
         type(c_ptr),intent(out)::p(8)

@@ -36,6 +36,17 @@ contains
         end do
         f_fd=0
     end function f_fd
+    integer function fdd(fddx,x,N)
+        integer,intent(in)::N
+        real*8,dimension(N,N),intent(out)::fddx
+        real*8,dimension(N),intent(in)::x
+        integer::i
+        fddx=0d0
+        do i=1,N
+            fddx(i,i)=12d0*x(i)*x(i)
+        end do
+        fdd=0
+    end function fdd
 end module quartic
 
 program main
@@ -59,6 +70,10 @@ program main
     write(*,*)'BFGS'
     call start(); call BFGS(f,fd,x,dim,ExactStep=0,Warning=.false.); write(*,'(A,ES24.16)')' BFGS0 ',norm2(x)
     call start(); call BFGS(f,fd,x,dim,ExactStep=0,f_fd=f_fd,Warning=.false.); write(*,'(A,ES24.16)')' BFGS0-f_fd ',norm2(x)
+    call start(); call BFGS(f,fd,x,dim,fdd=fdd,ExactStep=5,Warning=.false.); write(*,'(A,ES24.16)')' BFGS5-fdd ',norm2(x)
+    write(*,*)'Newton'
+    call start(); call NewtonRaphson(f,fd,x,dim,fdd=fdd,Warning=.false.); write(*,'(A,ES24.16)')' Newton ',norm2(x)
+    call start(); call NewtonRaphson(f,fd,x,dim,fdd=fdd,f_fd=f_fd,Strong=.false.,Warning=.false.); write(*,'(A,ES24.16)')' Newton-f_fd-Wolfe ',norm2(x)
     write(*,*)'Mission complete'
 contains
     subroutine start()

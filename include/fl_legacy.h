@@ -8,6 +8,7 @@
  *   __nonlinearoptimization_MOD_conjugategradient_basic  cpp/NonlinearOptimization.hpp:294-307   (NO.f90:2249)
  *   __nonlinearoptimization_MOD_conjugategradient        cpp/NonlinearOptimization.hpp:309-324   (NO.f90:193)
  *   __nonlinearoptimization_MOD_bfgs                     cpp/NonlinearOptimization.hpp:326-342   (NO.f90:632)
+ *   __nonlinearoptimization_MOD_newtonraphson            cpp/NonlinearOptimization.hpp:344-358   (NO.f90:1026)
  *   __nonlinearoptimization_MOD_augmentedlagrangian      cpp/NonlinearOptimization.hpp:367-392   (NO.f90:2005)
  *   __nonlinearoptimization_MOD_lbfgs                    (Fortran only in the reference)          (NO.f90:398)
  *   nonlinearoptimization_mp_*_                          the ifort manglings, hpp:11-123
@@ -17,11 +18,13 @@
  * them; all solver arithmetic runs on the GPU (reverse communication, fl_nlopt.h: fl_rci_*).
  * x is the only result (in/out), warnings go to stdout when Warning is true, like the reference.
  * Differences: an unknown Method prints the reference's message and returns instead of `stop`;
- * BFGS runs the ExactStep<=0 branch (ExactStep>0 is announced and ignored: not on the device yet).
  * AugmentedLagrangian: 'LBFGS', 'ConjugateGradient', 'BFGS' inner solvers ('NewtonRaphson' is refused with
  * the reference's "unsupported unconstrained solver" message); the wrappers L, Ld, L_Ld that compose the
  * caller's f, fd, c, cd (NO.f90:2193-2228) run on the host next to those callbacks, every inner solve on the GPU.
- * NewtonRaphson / TrustRegion legacy symbols are not exported.
+ * NewtonRaphson and BFGS with ExactStep > 0 call the caller's fdd on the host and ship the Hessian to the GPU
+ * (Cholesky solve / inverse there); without fdd the reference would call MKL djacobi -- not part of this build:
+ * BFGS then runs quasi-Newton updates only, NewtonRaphson refuses (both say so on stdout).
+ * TrustRegion (MKL RCI) is not exported (out of scope).
  */
 #ifndef FL_LEGACY_H
 #define FL_LEGACY_H
@@ -51,6 +54,10 @@ void __nonlinearoptimization_MOD_lbfgs(fl_f_cb f, fl_fd_cb fd, double *x, const 
 void __nonlinearoptimization_MOD_bfgs(fl_f_cb f, fl_fd_cb fd, double *x, const int *dim, fl_fdd_cb fdd,
                                       const int *ExactStep, fl_f_fd_cb f_fd, FL_LEGACY_COMMON_ARGS);
 
+void __nonlinearoptimization_MOD_newtonraphson(fl_f_cb f, fl_fd_cb fd, double *x, const int *dim, fl_fdd_cb fdd,
+                                               fl_f_fd_cb f_fd, FL_LEGACY_COMMON_ARGS);
+void nonlinearoptimization_mp_newtonraphson_(fl_f_cb f, fl_fd_cb fd, double *x, const int *dim, fl_fdd_cb fdd,
+                                             fl_f_fd_cb f_fd, FL_LEGACY_COMMON_ARGS);
 typedef void (*fl_c_cb)(double *cx, const double *x, const int *M, const int *N);    /* subroutine c(c(x),x,M,N)    */
 typedef void (*fl_cd_cb)(double *cdx, const double *x, const int *M, const int *N);  /* subroutine cd(c'(x),x,M,N): N x M */
 typedef int (*fl_cdd_cb)(double *cddx, const double *x, const int *M, const int *N); /* integer function cdd         */

@@ -201,9 +201,14 @@ int fl_augmented_lagrangian_batched(int solver, int objective, int batch, int n,
  * reference's evaluation counts.  First call: x_dev = initial guesses, f_dev/g_dev may be NULL.
  * Arrays whose bit was not requested are not read.  solver: FL_SOLVER_SD | CG | LBFGS | BFGS
  * (BFGS: ExactStep <= 0 path).  The handle owns its device buffers (history ring / inverse Hessians,
- * parked machine state). */
+ * parked machine state).
+ * Hessians (integer function fdd(f''(x),x,dim), NO.f90:37): with FL_SOLVER_NEWTON, or FL_SOLVER_BFGS and
+ * opt->exact_step > 0, a request may carry bit 4 (16): write f''(x) of the current (unchanged) x for that problem
+ * into the handle's buffer (fl_rci_hessian_buffer: [batch][n][ld] column-major, problem k at k*n*ld for Newton
+ * and at (3k+1)*n*ld for BFGS) and call fl_rci_step again; f_dev / g_dev are not read on that step. */
 typedef struct fl_rci fl_rci;
 int fl_rci_create(fl_rci **handle, int solver, int batch, int n, const fl_options *opt, void *stream);
+int fl_rci_hessian_buffer(fl_rci *handle, double **hessian_dev, int *ld);
 int fl_rci_step(fl_rci *handle, double *x_dev, const double *f_dev, const double *g_dev, int32_t *request_dev);
 /* copies the per-problem outputs (device pointers, each may be NULL) after all requests are 0 */
 int fl_rci_results(fl_rci *handle, double *f_dev, double *gg_dev, int32_t *iters_dev, int32_t *status_dev,

@@ -179,12 +179,12 @@ def test_fortran_use_fortranlibrary_smoke():
     vals = {}
     for line in out.stdout.splitlines():
         parts = line.split()
-        if len(parts) == 2 and parts[0] not in ("Steepest", "Conjugate"):
+        if len(parts) == 2 and parts[0] not in ("Steepest", "Conjugate", "Mission"):
             try:
                 vals[parts[0]] = float(parts[1])
             except ValueError:
                 pass
-    assert len(vals) == 10, out.stdout
+    assert len(vals) == 13, out.stdout
     for k, v in vals.items():
         assert v < (0.2 if k == "SD" else 1e-3), (k, v)  # steepest descent on a quartic crawls; the rest reach ~1e-5
 
@@ -243,3 +243,46 @@ def test_cpp_caller_links_and_runs_against_libFL():
     assert len(vals) == 5
     for k, v in vals.items():
         assert float(v) < (0.2 if k == "SD" else 1e-3 if not k.startswith("AugLag") else 1e-7), (k, v)
+
+
+FDD_CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int))
+
+
+@pytest.mark.parametrize("kind,n", [(O.QUARTIC, 10), (O.ROSENBROCK, 10), (O.ROSENBROCK, 40)])
+def test_legacy_newton_and_bfgs_with_host_hessian_callback(kind, n):
+    """NewtonRaphson (hpp:344-358) and BFGS with ExactStep > 0: the caller's fdd runs on the host, the Hessian is
+    shipped to the GPU (FL_REQ_H), Cholesky solve / inverse there; equal to the oracle bit for bit."""
+    FL = _fl()
+    rng = np.random.default_rng(n)
+    x0 = 1.0 + 0.1 * rng.uniform(-1, 1, n) if kind == O.ROSENBROCK else 0.1 * np.arange(1, n + 1)
+    f, fd, ffd, cnt, (T, E), P = _callbacks(kind, n)
+    lib = O.lib()
+    dp = C.POINTER(C.c_double)
+    lib.flo_prob_fdd.argtypes = [dp, dp, C.c_int, C.c_void_p]
+    nh = {"n": 0}
+
+    def fdd_py(H, x, dim):
+        nh["n"] += 1
+        lib.flo_prob_fdd(H, x, dim[0], C.byref(P))
+        return 0
+    fdd = FDD_CB(fdd_py)
+    dim = C.c_int(n)
+    x = x0.copy()
+    vals, refs = _common()
+    FL.__nonlinearoptimization_MOD_newtonraphson(f, fd, x.ctypes.data_as(dp), C.byref(dim), fdd, ffd, *refs)
+    ref = O.solve_batch(4, kind, x0, use_ffd=True, sum_mode=O.TREE, threads=T, ept=E)
+    assert np.array_equal(x, ref["x"][0])
+    assert nh["n"] == ref["iters"][0] + 1 or ref["status"][0] != O.MAXIT
+    x = x0.copy()
+    es = C.c_int(5)
+    FL.__nonlinearoptimization_MOD_bfgs(f, fd, x.ctypes.data_as(dp), C.byref(dim), fdd, C.byref(es), None, *refs)
+    ref = O.solve_batch(O.BFGS, kind, x0, opts=O.defaults(exact_step=5), bfgs_form=1, sum_mode=O.TREE, threads=T, ept=E)
+    assert np.array_equal(x, ref["x"][0])
+    # without fdd: BFGS falls back to quasi-Newton updates (ExactStep=0), NewtonRaphson refuses and leaves x alone
+    x = x0.copy()
+    FL.__nonlinearoptimization_MOD_bfgs(f, fd, x.ctypes.data_as(dp), C.byref(dim), None, C.byref(es), None, *refs)
+    ref = O.solve_batch(O.BFGS, kind, x0, opts=O.defaults(exact_step=0), bfgs_form=1, sum_mode=O.TREE, threads=T, ept=E)
+    assert np.array_equal(x, ref["x"][0])
+    x = x0.copy()
+    FL.__nonlinearoptimization_MOD_newtonraphson(f, fd, x.ctypes.data_as(dp), C.byref(dim), None, None, *refs)
+    assert np.array_equal(x, x0)
