@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--workload", default="lbfgs_quad1024", choices=["lbfgs_quad1024", "lbfgs_rosen256"])
     ap.add_argument("--cpu-sample", type=int, default=-1, help="problems timed on the CPU (-1 auto, 0 skip)")
     ap.add_argument("--no-two-loop", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL over xGMI); gloo only to "
+                    "rehearse the N > 1 orchestration with several ranks on ONE GPU (FL_BENCH_ONE_DEVICE=1)")
     args = ap.parse_args()
 
     import numpy as np
@@ -86,11 +88,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("FL_BENCH_ONE_DEVICE"):  # rehearsal: every rank on GPU 0 (needs --backend gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     if args.workload == "lbfgs_rosen256":
         args.n, objective = 256, NLO.ROSENBROCK
@@ -145,8 +152,9 @@ def main():
         out = step(True)
     sync()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    iters_step = out["iters"].to(torch.int64).sum().reshape(1)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")
+    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
+    iters_step = out["iters"].to(torch.int64).sum().reshape(1).to(cdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(iters_step, op=dist.ReduceOp.SUM)

@@ -22,11 +22,16 @@ def gather_results(results, dst=0, group=None):
     """
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    # RCCL ("nccl") moves device tensors directly over xGMI; gloo (CPU tests, single-GPU rehearsals) needs host tensors
+    stage = dist.get_backend(group) == "gloo"
     out = {} if rank == dst else None
     for name in sorted(results):
         t = results[name].contiguous()
+        dev = t.device
+        if stage and t.is_cuda:
+            t = t.cpu()
         bufs = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
         dist.gather(t, bufs, dst=dst, group=group)
         if rank == dst:
-            out[name] = torch.cat(bufs, dim=0)
+            out[name] = torch.cat(bufs, dim=0).to(dev)
     return out
