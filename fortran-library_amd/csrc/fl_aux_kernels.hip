@@ -152,18 +152,22 @@ __global__ __launch_bounds__(NW * 64) void two_loop_kernel(int n, int mem, int r
             down(j + 1, sB, yB);
         }
     }
-    fetch(mem - 1, sA, yA);
     const double rr = rho_s[recent];
 #pragma unroll
     for (int k = 0; k < EPT; ++k) p[k] = p[k] / rr / yy;
     __syncthreads();
-    for (int j = mem - 1; j >= 0; j -= 2) {
+    // buffers by parity of j (even -> A, odd -> B): the oldest pair is still resident from the way down
+    int j = mem - 1;
+    if ((j & 1) == 0) {
         if (j - 1 >= 0) fetch(j - 1, sB, yB);
         upw(j, sA, yA);
-        if (j - 1 >= 0) {
-            if (j - 2 >= 0) fetch(j - 2, sA, yA);
-            upw(j - 1, sB, yB);
-        }
+        --j;
+    }
+    for (; j >= 1; j -= 2) {
+        fetch(j - 1, sA, yA);
+        upw(j, sB, yB);
+        if (j - 2 >= 0) fetch(j - 2, sB, yB);
+        upw(j - 1, sA, yA);
     }
     double *prow = p_all + (size_t)prob * n;
 #pragma unroll

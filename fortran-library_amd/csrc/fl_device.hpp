@@ -757,18 +757,17 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
         recent = (recent + 1 == mem) ? 0 : recent + 1; // recent=mod(recent+1,mem)
         if (cnt < mem) ++cnt;
         double r[2];
-        {
-            double sv[EPT], yv[EPT];
+        // the newest pair stays in registers for both loops (its two row reads per loop never leave the CU)
+        double sv[EPT], yv[EPT];
 #pragma unroll
-            for (int k = 0; k < EPT; ++k) {
-                sv[k] = x[k] - x0[k];
-                yv[k] = g[k] - g0[k];
-            }
-            store_pad<NW, EPT>(hist + (size_t)(2 * recent) * NPAD, sv);
-            store_pad<NW, EPT>(hist + (size_t)(2 * recent + 1) * NPAD, yv);
-            r[0] = dot_part<EPT>(yv, sv);
-            r[1] = dot_part<EPT>(yv, yv);
+        for (int k = 0; k < EPT; ++k) {
+            sv[k] = x[k] - x0[k];
+            yv[k] = g[k] - g0[k];
         }
+        store_pad<NW, EPT>(hist + (size_t)(2 * recent) * NPAD, sv);
+        store_pad<NW, EPT>(hist + (size_t)(2 * recent + 1) * NPAD, yv);
+        r[0] = dot_part<EPT>(yv, sv);
+        r[1] = dot_part<EPT>(yv, yv);
         R.run(r);
         if (threadIdx.x == 0) rho_s[recent] = 1.0 / r[0]; // rho=1/(y.s): no curvature safeguard (NO.f90:623)
         rho_recent = uni(1.0 / r[0]);
@@ -807,26 +806,36 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
 #pragma unroll
             for (int k = 0; k < EPT; ++k) p[k] = p[k] + co * s_[k];
         };
-        fetch(0, sA, yA);
-        for (int j = 0; j < cnt; j += 2) {
-            if (j + 1 < cnt) fetch(j + 1, sB, yB);
-            down(j, sA, yA);
+        // Row buffers by parity of j (j-th newest pair): odd j -> B, even j -> A; on the way down j = 0 is the
+        // pair just formed in registers (sv, yv).  The oldest pair is used twice in a row (last step down, first
+        // step up) and is not fetched again; every other row is in flight one step ahead of its use.
+        if (cnt > 1) fetch(1, sB, yB);
+        down(0, sv, yv);
+        for (int j = 1; j < cnt; j += 2) {
+            if (j + 1 < cnt) fetch(j + 1, sA, yA);
+            down(j, sB, yB);
             if (j + 1 < cnt) {
-                if (j + 2 < cnt) fetch(j + 2, sA, yA);
-                down(j + 1, sB, yB);
+                if (j + 2 < cnt) fetch(j + 2, sB, yB);
+                down(j + 1, sA, yA);
             }
         }
-        fetch(cnt - 1, sA, yA); // oldest pair first on the way back: start its loads before the scaling
 #pragma unroll
         for (int k = 0; k < EPT; ++k) p[k] = p[k] / rho_recent / yy_recent; // p=p/rho(recent)/(y.y)
         __syncthreads(); // alpha_s written by thread 0 is visible (NW == 1 has no reduction barrier)
-        for (int j = cnt - 1; j >= 0; j -= 2) {
+        // (holding the newest pair in registers across the whole recursion as well was measured: the kernel
+        //  goes from 112 to 252 VGPRs, one wave per SIMD, 18.4 instead of 27.8 M it/s -- so it is re-read here)
+        int j = cnt - 1;
+        if (cnt == 1) fetch(0, sA, yA);
+        if ((j & 1) == 0) { // even top: resident in A
             if (j - 1 >= 0) fetch(j - 1, sB, yB);
             upw(j, sA, yA);
-            if (j - 1 >= 0) {
-                if (j - 2 >= 0) fetch(j - 2, sA, yA);
-                upw(j - 1, sB, yB);
-            }
+            --j;
+        }
+        for (; j >= 1; j -= 2) { // j odd: resident / prefetched in B
+            fetch(j - 1, sA, yA);
+            upw(j, sB, yB);
+            if (j - 2 >= 0) fetch(j - 2, sB, yB);
+            upw(j - 1, sA, yA);
         }
 #pragma unroll
         for (int k = 0; k < EPT; ++k) p[k] = -p[k];

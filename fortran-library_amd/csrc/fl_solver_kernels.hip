@@ -24,7 +24,10 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG>
 __global__ __launch_bounds__(NW * 64) FL_OCC_ATTR void fl_solve_kernel(SolveArgs A)
 {
     using S = Solver<NW, EPT, OBJ, METHOD, AUG>;
-    __shared__ __attribute__((aligned(16))) double lds[S::LDS_TOTAL];
+#ifndef FL_LDS_PAD // tuning knob: extra LDS per workgroup caps the workgroups resident per CU
+#define FL_LDS_PAD 0
+#endif
+    __shared__ __attribute__((aligned(16))) double lds[S::LDS_TOTAL + FL_LDS_PAD];
     S s(A, lds);
     s.init();
     int rq = s.start();

@@ -3,6 +3,6 @@
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 for round in 1 2; do
 for so in $R/fortran-library_amd/lib/variants/libFL_*.so; do
-  FL_LIBRARY=$so python $R/bench.py --cpu-sample 0 --no-two-loop --steps 3 --warmup 1 2>/dev/null | python -c "
+  FL_LIBRARY=$so python $R/bench.py --cpu-sample 0 --no-two-loop --steps 3 --warmup 1 2>/tmp/ab_err.txt | python -c "
 import json,sys; r=json.loads(sys.stdin.read()); print('$(basename $so)', round(r['value']/1e6,2), 'Mit/s', round(r['ms_per_step'],1), 'ms')"
 done; done
