@@ -317,6 +317,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
     // augmented Lagrangian
     double miu, cc;
     int outer_it, inner_iters_total;
+    int blk[AUG ? EPT : 1]; // constraint block of each of the thread's elements (-1 = padding)
 
     enum { PH_INIT = 0, PH_LS = 1, PH_DONE = 2, PH_HESS = 3 };
 
@@ -356,6 +357,12 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
         cc = 0.0;
         miu = 0.0;
         if constexpr (AUG) {
+            const int w = n / A.aug_m;
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+                const int e = G::e0(k >> 1) + (k & 1);
+                blk[k] = (e < n) ? e / w : -1;
+            }
             miu = A.miu0 > 1.0 ? A.miu0 : 1.0; // miu=max(1d0,miu0)
             if ((int)threadIdx.x < A.aug_m) lds[L_LAM + threadIdx.x] = A.lambda[(size_t)prob * A.aug_m + threadIdx.x];
             __syncthreads();
@@ -375,13 +382,21 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
         for (int k = 0; k < EPT; ++k) x[k] = x0[k] + at * p[k];
     }
     // f, g.p, g.g at x; with AUG the objective is the augmented Lagrangian
-    __device__ __forceinline__ void evaluate(double &f, double &gp, double &ggo)
+    // WANT_G = false (augmented Lagrangian only): an objective-only trial -- the reference's shrink loop
+    // calls L, not Ld, ~45 times per gradient -- skips the gradient, the constraint
+    // Jacobian term and the g.p / g.g reduction; g, gp, ggo are then left untouched.
+    template <bool WANT_G = true> __device__ __forceinline__ void evaluate(double &f, double &gp, double &ggo)
     {
         double r[4];
-        obj.eval(x, g, r[0], r[1], n, lds + L_XS);
+        if constexpr (AUG && !WANT_G) {
+            double gl[EPT]; // dead: the compiler drops the gradient arithmetic
+            obj.eval(x, gl, r[0], r[1], n, lds + L_XS);
+        } else {
+            obj.eval(x, g, r[0], r[1], n, lds + L_XS);
+        }
         if constexpr (AUG) {
             // c_j: masked full-width sums of x^2 (one reduction of aug_m values with the objective's)
-            const int m = A.aug_m, w = n / m;
+            const int m = A.aug_m;
             double cj[FL_MAX_CONSTRAINTS];
 #pragma unroll
             for (int j = 0; j < FL_MAX_CONSTRAINTS; ++j) {
@@ -390,27 +405,41 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
                     double acc = 0.0;
 #pragma unroll
                     for (int k = 0; k < EPT; ++k) {
-                        const int e = G::e0(k >> 1) + (k & 1);
-                        const double t = (e < n && e / w == j) ? x[k] * x[k] : 0.0;
+                        const double t = (blk[k] == j) ? x[k] * x[k] : 0.0;
                         acc = (k == 0) ? t : acc + t;
                     }
                     cj[j] = acc;
                 }
             }
             double r2[2] = {r[0], r[1]};
-            R.run(r2);
             double *cxs = lds + L_CX;
             __syncthreads(); // readers of the previous trial's c(x) are done
+            if (m <= 8) { // the objective's two sums and up to 8 constraints in ONE reduction phase
+                double q[10];
+                q[0] = r2[0];
+                q[1] = r2[1];
 #pragma unroll
-            for (int j0 = 0; j0 < FL_MAX_CONSTRAINTS; j0 += 4) { // reduce the constraints four at a time
-                if (j0 < m) {
-                    double q[4];
+                for (int u = 0; u < 8; ++u) q[2 + u] = cj[u];
+                R.run(q);
+                r2[0] = q[0];
+                r2[1] = q[1];
+                if (threadIdx.x == 0) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) q[u] = cj[j0 + u];
-                    R.run(q);
-                    if (threadIdx.x == 0) {
+                    for (int u = 0; u < 8; ++u) cxs[u] = q[2 + u] - 1.0;
+                }
+            } else {
+                R.run(r2);
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) cxs[j0 + u] = q[u] - 1.0;
+                for (int j0 = 0; j0 < FL_MAX_CONSTRAINTS; j0 += 4) { // the constraints four at a time
+                    if (j0 < m) {
+                        double q[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) q[u] = cj[j0 + u];
+                        R.run(q);
+                        if (threadIdx.x == 0) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) cxs[j0 + u] = q[u] - 1.0;
+                        }
                     }
                 }
             }
@@ -422,11 +451,11 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
                 c2 = c2 + cxs[j] * cxs[j];
             }
             f = uni(Obj::combine(r2[0], r2[1]) - lc + miu / 2.0 * c2);
+            if constexpr (!WANT_G) return;
 #pragma unroll
             for (int k = 0; k < EPT; ++k) {
-                const int e = G::e0(k >> 1) + (k & 1);
-                if (e < n) {
-                    const int j = e / w;
+                if (blk[k] >= 0) {
+                    const int j = blk[k];
                     const double v = miu * cxs[j] - lds[L_LAM + j];
                     g[k] = g[k] + (2.0 * x[k]) * v; // Ldx=Ldx+matmul(cdx,miu*cx-lambda)
                 }

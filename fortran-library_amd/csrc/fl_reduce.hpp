@@ -49,7 +49,7 @@ __device__ __forceinline__ double wave_allreduce(double v)
 template <int NW> struct Reducer {
     double *slots; // LDS [2][NVMAX][NW]
     int parity;
-    static constexpr int NVMAX = 4;
+    static constexpr int NVMAX = 10;
     template <int NV> __device__ __forceinline__ void run(double (&v)[NV])
     {
 #pragma unroll

@@ -32,10 +32,20 @@ __global__ __launch_bounds__(NW * 64) FL_OCC_ATTR void fl_solve_kernel(SolveArgs
     s.init();
     int rq = s.start();
     double fv = 0.0, pv = 0.0, gg = 0.0;
+    bool have_g = false; // augmented Lagrangian: objective-only trials skip the gradient until it is asked for
     while (rq) {
         if (!(rq & FL_REQ_SAME)) {
             if (!(rq & FL_REQ_NOMOVE)) s.move(s.request_point());
-            s.evaluate(fv, pv, gg);
+            if (AUG && !(rq & FL_REQ_G)) {
+                s.template evaluate<false>(fv, pv, gg);
+                have_g = false;
+            } else {
+                s.template evaluate<true>(fv, pv, gg);
+                have_g = true;
+            }
+        } else if (AUG && (rq & FL_REQ_G) && !have_g) { // gradient at the point whose objective is already known
+            s.template evaluate<true>(fv, pv, gg);
+            have_g = true;
         }
         rq = s.advance(fv, pv, gg);
     }
