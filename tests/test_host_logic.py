@@ -109,3 +109,36 @@ def _grad(kind, x, d, b):
     g[:-1] += -400 * x[:-1] * u - 2 * (1 - x[:-1])
     g[1:] += 200 * u
     return g
+
+
+def test_strong_wolfe_quirk_path_is_exercised_and_matches():
+    """StrongWolfe (no f_fd) keeps looping after zoom in its grow branch (NO.f90:1507-1514) while
+    StrongWolfe_fdwithf returns (1628-1632): with Increment = 3, c2 = 0.1 the two variants end differently in
+    hundreds of searches -- and in every one the machine equals the oracle's structured restatement."""
+    drv = _driver()
+    dp = C.POINTER(C.c_double)
+    args = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, dp, dp, dp, dp, C.c_double, dp, dp,
+            dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    drv.ls_machine_run.argtypes = args
+    drv.ls_oracle_run.argtypes = args
+    rng = np.random.default_rng(0)
+    n, differ = 24, 0
+    for kind in (O.QUARTIC, O.DIAGQUAD):
+        for _ in range(600):
+            d = 1 + rng.uniform(0, 99, n)
+            b = rng.uniform(-1, 1, n)
+            x = rng.uniform(-1.5, 1.5, n)
+            g = _grad(kind, x, d, b)
+            p = -g * rng.uniform(0.5, 1.5, n)
+            fx0 = float(O.solve_batch(O.SD, kind, x, d=d, b=b, opts=O.defaults(maxit=0))["f"][0])
+            a0 = float(10.0 ** rng.uniform(-6, 0))
+            res = []
+            for fn, fused in ((drv.ls_machine_run, 0), (drv.ls_oracle_run, 0), (drv.ls_machine_run, 1), (drv.ls_oracle_run, 1)):
+                xx, gg = x.copy(), np.zeros(n)
+                a, fx, nf, ng = C.c_double(a0), C.c_double(fx0), C.c_int(0), C.c_int(0)
+                fn(1, fused, 1e-4, 0.1, 3.0, kind, n, xx.ctypes.data_as(dp), p.ctypes.data_as(dp), C.byref(a), C.byref(fx),
+                   float(g @ p), d.ctypes.data_as(dp), b.ctypes.data_as(dp), gg.ctypes.data_as(dp), C.byref(nf), C.byref(ng))
+                res.append((a.value, fx.value, nf.value, ng.value, xx.tobytes()))
+            assert res[0] == res[1] and res[2] == res[3]
+            differ += res[0][:2] != res[2][:2]
+    assert differ > 50
