@@ -93,6 +93,19 @@ def test_rosenbrock_n10_standard_start(solver, kw):
     _assert_bitexact(g, o)
 
 
+@pytest.mark.parametrize("solver", [O.SD, O.CG, O.LBFGS])
+@pytest.mark.parametrize("ffd", [False, True])
+@pytest.mark.parametrize("kind,n", [(O.QUARTIC, 10), (O.DIAGQUAD, 64)])
+def test_overshooting_line_search_branches_bitexact(solver, ffd, kind, n):
+    """Increment = 3 with WolfeConst2 = 0.1 overshoots into the "curve heading up" branches of StrongWolfe, incl.
+    the zoom-then-keep-looping path of the non-fused variant (NO.f90:1507-1514 vs 1628-1632)"""
+    rng = np.random.default_rng(11 + n)
+    x0, d, b = rng.uniform(-1.5, 1.5, (12, n)), 1 + rng.uniform(0, 99, (12, n)), rng.uniform(-1, 1, (12, n))
+    kw = {"f_fd": True} if ffd else {}
+    g, o = _both(solver, kind, x0, d, b, WolfeConst2=0.1, Increment=3.0, MaxIteration=80, **kw)
+    _assert_bitexact(g, o)
+
+
 @pytest.mark.parametrize("n", [1, 2, 7, 63, 129, 255, 256, 257, 513, 1000, 1024, 2048, 4096])
 def test_rosenbrock_lbfgs_sizes_and_ragged_n(n):
     """every geometry of the kernel, odd n (unaligned rows), n not filling the workgroup"""
