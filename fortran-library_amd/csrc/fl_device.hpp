@@ -294,7 +294,27 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
     static constexpr int L_G0 = (L_XS + (Obj::LDS_DOUBLES > 0 ? Obj::LDS_DOUBLES : 0) + 1) & ~1;
     // BFGS: s, q, g broadcast arrays; the first one doubles as the g_old parking slot (the
     // broadcast arrays are only live inside direction_bfgs, g_old only outside it)
-    static constexpr int L_BF = L_G0 + ((NEEDS_G0 && METHOD != FL_SOLVER_BFGS) ? NPAD : 0);
+    // L-BFGS, fused kernels only: the LDS_PAIRS newest (s, y) pairs also live in LDS (every thread reads back only
+    // the elements it wrote -- the rows are private spill space, no barrier involved), so the recursion fetches
+    // 4*(cnt - LDS_PAIRS) - 2 rows from HBM instead of 4*cnt - 4.  Sized to leave the occupancy the registers
+    // allow (2 waves / SIMD = 8/NW workgroups per CU, 20*NW KiB of LDS each; a pair takes NW*EPT KiB).
+    // g_old is parked in the y row of the slot the next pair will overwrite.
+#ifndef FL_LDS_PAIRS_E8
+#define FL_LDS_PAIRS_E8 2
+#endif
+    // measured (profiles/r01/lds_pairs_ab.txt): n=1024 (2x8) 226.5 -> 220.2 ms with 2 pairs; the small geometries
+    // lose occupancy to the LDS footprint (n=256, 1x4: 3.26 ms with 0 pairs, 4.08 with 2, 3.56 with 4) -> 0 there
+#ifndef FL_LDS_PAIRS_E4
+#define FL_LDS_PAIRS_E4 0
+#endif
+#ifndef FL_LDS_PAIRS_E2
+#define FL_LDS_PAIRS_E2 0
+#endif
+#define FL_LDS_PAIRS(NW_, EPT_) ((EPT_) >= 8 ? FL_LDS_PAIRS_E8 : ((EPT_) == 4 ? FL_LDS_PAIRS_E4 : FL_LDS_PAIRS_E2))
+    static constexpr int LDS_PAIRS_FIT = (2560 * NW - L_G0) / (2 * NPAD);
+    static constexpr int LDS_PAIRS_WANT = (METHOD == FL_SOLVER_LBFGS && OBJ != FL_OBJ_EXTERNAL) ? FL_LDS_PAIRS(NW, EPT) : 0;
+    static constexpr int LDS_PAIRS = LDS_PAIRS_WANT < LDS_PAIRS_FIT ? LDS_PAIRS_WANT : LDS_PAIRS_FIT;
+    static constexpr int L_BF = L_G0 + ((NEEDS_G0 && METHOD != FL_SOLVER_BFGS) ? (LDS_PAIRS > 0 ? 2 * LDS_PAIRS * NPAD : NPAD) : 0);
     // Newton: one row buffer for the Cholesky kernels (BFGS reuses its broadcast arrays)
     static constexpr int LDS_TOTAL = L_BF + (METHOD == FL_SOLVER_BFGS ? 3 * NPAD : (METHOD == FL_SOLVER_NEWTON ? NPAD : 0));
     using DN = Dense<NW, EPT>;
@@ -309,6 +329,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
     double fnew, gg, pp, phid, phidold, a;
     int iters, nf, ng, status, phase, pending;
     int recent, cnt;    // L-BFGS ring
+    int lrec;           // slot of the newest pair in the LDS ring (LDS_PAIRS > 0)
     int main_it, h_valid; // BFGS / Newton: main-loop iteration counter (iIteration), inverse Hessian initialised
     int hess_stage;       // reverse communication: where to resume once the caller has supplied the Hessian
     static constexpr bool HESS_RCI = (OBJ == FL_OBJ_EXTERNAL);
@@ -335,6 +356,18 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
         if constexpr (METHOD == FL_SOLVER_NEWTON) return A.hist + (size_t)prob * (size_t)n * NPAD;
         return nullptr;
     }
+    // LDS rows of the slot-th pair of the LDS ring (s row, then y row)
+    __device__ __forceinline__ double *lds_pair(int slot) const { return lds + L_G0 + (size_t)(2 * slot) * NPAD; }
+    // where g_old waits during the line search
+    __device__ __forceinline__ double *g0_park() const
+    {
+        if constexpr (LDS_PAIRS > 0) {
+            const int next = (lrec + 1 == LDS_PAIRS) ? 0 : lrec + 1;
+            return lds_pair(next) + NPAD;
+        } else {
+            return lds + L_G0;
+        }
+    }
 
     // ---------------------------------------------------------------- setup
     __device__ __forceinline__ void init()
@@ -346,6 +379,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
         iters = nf = ng = 0;
         status = FL_STATUS_CONVERGED;
         recent = -1;
+        lrec = -1;
         cnt = 0;
         main_it = 0;
         h_valid = 0;
@@ -517,7 +551,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
         }
 #pragma unroll
         for (int k = 0; k < EPT; ++k) x0[k] = x[k]; // xold=x (doubles as the line search's x0)
-        if constexpr (NEEDS_G0) store_pad<NW, EPT>(lds + L_G0, g); // fdold=fdnew, parked in LDS
+        if constexpr (NEEDS_G0) store_pad<NW, EPT>(g0_park(), g); // fdold=fdnew, parked in LDS
         phidold = phid;
         const int strong = (METHOD == FL_SOLVER_CG && A.cg_method == FL_CG_PR) ? 1 : A.strong;
         phase = PH_LS;
@@ -680,7 +714,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
     __device__ __forceinline__ int direction_and_begin()
     {
         double g0[EPT];
-        if constexpr (NEEDS_G0) load_pad<NW, EPT>(lds + L_G0, g0);
+        if constexpr (NEEDS_G0) load_pad<NW, EPT>(g0_park(), g0);
         if constexpr (METHOD == FL_SOLVER_SD) { // NO.f90:185-186
 #pragma unroll
             for (int k = 0; k < EPT; ++k) p[k] = -g[k];
@@ -738,6 +772,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
             }
             // fresh inner solve from the current x: every solver starts with an evaluation of L, L'
             recent = -1;
+            lrec = -1;
             cnt = 0;
             phase = PH_INIT;
             return FL_REQ_F | FL_REQ_G | FL_REQ_NOMOVE;
@@ -793,8 +828,16 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
             sv[k] = x[k] - x0[k];
             yv[k] = g[k] - g0[k];
         }
-        store_pad<NW, EPT>(hist + (size_t)(2 * recent) * NPAD, sv);
-        store_pad<NW, EPT>(hist + (size_t)(2 * recent + 1) * NPAD, yv);
+        constexpr int K = LDS_PAIRS;
+        if constexpr (K > 0) {
+            lrec = (lrec + 1 == K) ? 0 : lrec + 1; // g_old was parked in this slot's y row (already in g0)
+            store_pad<NW, EPT>(lds_pair(lrec), sv);
+            store_pad<NW, EPT>(lds_pair(lrec) + NPAD, yv);
+        }
+        if (K == 0 || mem > K) { // a ring that fits in LDS never touches HBM
+            store_pad<NW, EPT>(hist + (size_t)(2 * recent) * NPAD, sv);
+            store_pad<NW, EPT>(hist + (size_t)(2 * recent + 1) * NPAD, yv);
+        }
         r[0] = dot_part<EPT>(yv, sv);
         r[1] = dot_part<EPT>(yv, yv);
         R.run(r);
@@ -813,9 +856,16 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
             return s < 0 ? s + mem : s;
         };
         auto fetch = [&](int j, double (&s_)[EPT], double (&y_)[EPT]) {
-            const double *row = hist + (size_t)(2 * slot_of(j)) * NPAD;
-            load_pad<NW, EPT>(row, s_);
-            load_pad<NW, EPT>(row + NPAD, y_);
+            if (K > 0 && j < K) { // one of the K newest: from the LDS ring (separate branches keep ds_read / global_load)
+                const int ls = lrec - j;
+                const double *row = lds_pair(ls < 0 ? ls + K : ls);
+                load_pad<NW, EPT>(row, s_);
+                load_pad<NW, EPT>(row + NPAD, y_);
+            } else {
+                const double *row = hist + (size_t)(2 * slot_of(j)) * NPAD;
+                load_pad<NW, EPT>(row, s_);
+                load_pad<NW, EPT>(row + NPAD, y_);
+            }
         };
         auto down = [&](int j, const double (&s_)[EPT], const double (&y_)[EPT]) {
             const int sl = slot_of(j);

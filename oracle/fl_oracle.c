@@ -53,11 +53,14 @@ static double tree_reduce(int n, const double *a, const double *b)
             }
             lane[l] = acc;
         }
-        for (int off = 1; off < 64; off <<= 1) { /* xor butterfly 1,2,4,8,16,32 */
-            for (int l = 0; l < 64; ++l) tmp[l] = lane[l] + lane[l ^ off];
-            memcpy(lane, tmp, sizeof lane);
-        }
-        wave[w] = lane[0];
+        /* the kernels' wave tree (csrc/fl_reduce.hpp): halves, quarter rows, then mirror steps inside a row */
+        for (int l = 0; l < 32; ++l) tmp[l] = lane[l] + lane[l + 32];
+        for (int l = 0; l < 16; ++l) lane[l] = tmp[l] + tmp[l + 16];
+        for (int i = 0; i < 8; ++i) tmp[i] = lane[i] + lane[15 - i];
+        for (int i = 0; i < 4; ++i) lane[i] = tmp[i] + tmp[7 - i];
+        tmp[0] = lane[0] + lane[2];
+        tmp[1] = lane[1] + lane[3];
+        wave[w] = tmp[0] + tmp[1];
     }
     double tot = wave[0];
     for (int w = 1; w < NW; ++w) tot = tot + wave[w];

@@ -5,7 +5,7 @@
 R=$(cd "$(dirname "$0")/.." && pwd)
 P=$R/fortran-library_amd
 mkdir -p $P/lib/variants /tmp/flvar
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -DFL_ONLY_BENCH"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math ${FL_FULL:--DFL_ONLY_BENCH}"  # FL_FULL=" " builds every instantiation
 build() {
   name=$1; flags=$2; d=/tmp/flvar/$name; mkdir -p $d
   for src in fl_solver_kernels fl_aux_kernels fl_bfgs_gemm fl_dense_kernels; do
