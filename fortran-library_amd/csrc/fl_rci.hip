@@ -15,6 +15,7 @@
 // manglings): steepestdescent, conjugategradient(_basic), lbfgs, bfgs -- batch of one,
 // callbacks evaluated on the host, x copied device <-> host per evaluation.
 #include "fl_device.hpp"
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <functional>
@@ -251,6 +252,26 @@ static HostObjective host_objective(f_cb f, fd_cb fd, ffd_cb f_fd)
     return ob;
 }
 
+// fdd absent: the reference differentiates f' numerically with MKL's djacobi(fd_j,dim,dim,H,x,1d-8) (NO.f90:676,
+// 981, 1067, 1258) -- central differences; MKL is closed and the reference does not state its step rule, so this
+// branch is "parity unpinned" (DESIGN.md).  Here: column j = (f'(x + h e_j) - f'(x - h e_j)) / (2h),
+// h = 1e-8 * max(1, |x_j|), 2n gradient calls per Hessian like djacobi.
+static std::function<void(double *, const double *, int)> central_difference_hessian(fd_cb fd)
+{
+    return [fd](double *H, const double *x, int n) {
+        std::vector<double> xp(x, x + n), gp(n), gm(n);
+        for (int j = 0; j < n; ++j) {
+            const double h = 1e-8 * std::fmax(1.0, std::fabs(x[j]));
+            xp[j] = x[j] + h;
+            fd(gp.data(), xp.data(), n);
+            xp[j] = x[j] - h;
+            fd(gm.data(), xp.data(), n);
+            xp[j] = x[j];
+            for (int i = 0; i < n; ++i) H[(size_t)j * n + i] = (gp[i] - gm[i]) / (2.0 * h);
+        }
+    };
+}
+
 static int legacy_solve(int solver, const char *name, const HostObjective &ob, double *x, int n, const fl_options &o,
                         int warn)
 {
@@ -408,9 +429,9 @@ void __nonlinearoptimization_MOD_lbfgs(f_cb f, fd_cb fd, double *x, const int *d
 }
 
 // subroutine BFGS(f,fd,x,dim,fdd,ExactStep,f_fd,Strong,...)  NO.f90:632 ; hpp:326-342.
-// The device path is the reference's ExactStep<=0 branch (rank-2 updates only).  ExactStep>0 asks
-// for an exact inverse Hessian every ExactStep iterations (fdd or MKL djacobi + dpotri, NO.f90:674-682,
-// 949-956): not on the device yet -- said once on stdout when Warning is on, then solved without.
+// ExactStep>0 asks for an exact inverse Hessian every ExactStep iterations (NO.f90:674-682, 949-956): the
+// machine requests it (FL_REQ_H), fdd -- or central differences of fd when fdd is absent -- answers on the
+// host, Cholesky + inverse run on the device.
 void __nonlinearoptimization_MOD_bfgs(f_cb f, fd_cb fd, double *x, const int *dim, fdd_cb fdd, const int *ExactStep,
                                       ffd_cb f_fd, FL_LEGACY_COMMON)
 {
@@ -422,30 +443,22 @@ void __nonlinearoptimization_MOD_bfgs(f_cb f, fd_cb fd, double *x, const int *di
     HostObjective ob = host_objective(f, fd, f_fd);
     if (freq > 0 && fdd) {
         ob.fdd = [fdd](double *H, const double *xx, int n) { (void)fdd(H, xx, n); };
-    } else if (freq > 0) { // fdd absent: the reference differentiates numerically with MKL djacobi (NO.f90:676)
-        o.exact_step = 0;
-        if (warn_of(Warning))
-            std::printf(" BFGS (MI355X): no analytical Hessian (fdd) given and MKL djacobi is not part of this build;"
-                        " continuing with quasi-Newton updates only (ExactStep=0)\n");
+    } else if (freq > 0) { // fdd absent: numerical Hessian in place of MKL djacobi (NO.f90:676, 981)
+        ob.fdd = central_difference_hessian(fd);
     }
     legacy_solve(FL_SOLVER_BFGS, "BFGS", ob, x, *dim, o, warn_of(Warning));
 }
 
-// subroutine NewtonRaphson(f,fd,x,dim,fdd,f_fd,Strong,...)  NO.f90:1026 ; hpp:344-358.  fdd is required here
-// (the reference falls back to MKL djacobi without it, NO.f90:1066).
+// subroutine NewtonRaphson(f,fd,x,dim,fdd,f_fd,Strong,...)  NO.f90:1026 ; hpp:344-358.
 void __nonlinearoptimization_MOD_newtonraphson(f_cb f, fd_cb fd, double *x, const int *dim, fdd_cb fdd, ffd_cb f_fd,
                                                FL_LEGACY_COMMON)
 {
-    if (!fdd) {
-        std::printf(" Newton-Raphson (MI355X): an analytical Hessian (fdd) is required; MKL djacobi is not part of"
-                    " this build.  x is unchanged\n");
-        return;
-    }
     fl_options o;
     legacy_options(o, FL_SOLVER_NEWTON, Strong, MaxIteration, Precision, MinStepLength, WolfeConst1, WolfeConst2,
                    Increment, f_fd);
     HostObjective ob = host_objective(f, fd, f_fd);
-    ob.fdd = [fdd](double *H, const double *xx, int n) { (void)fdd(H, xx, n); };
+    if (fdd) ob.fdd = [fdd](double *H, const double *xx, int n) { (void)fdd(H, xx, n); };
+    else ob.fdd = central_difference_hessian(fd); // NO.f90:1066-1067
     legacy_solve(FL_SOLVER_NEWTON, "Newton-Raphson", ob, x, *dim, o, warn_of(Warning));
 }
 void nonlinearoptimization_mp_newtonraphson_(f_cb f, fd_cb fd, double *x, const int *dim, fdd_cb fdd, ffd_cb f_fd,

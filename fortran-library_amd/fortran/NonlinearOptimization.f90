@@ -13,11 +13,12 @@
 !  SteepestDescent   <- reference NonlinearOptimization.f90:55
 !  ConjugateGradient <- reference NonlinearOptimization.f90:193 (Method = 'DY' | 'PR')
 !  LBFGS             <- reference NonlinearOptimization.f90:398
-!  BFGS              <- reference NonlinearOptimization.f90:632 (ExactStep <= 0 branch on the device)
+!  BFGS              <- reference NonlinearOptimization.f90:632 (ExactStep > 0: Hessian from fdd or central differences)
 !New: LBFGS_batched / ConjugateGradient_batched -- batches of independent problems with
 !device-resident data and built-in objectives (include/fl_nlopt.h).
-!  NewtonRaphson     <- reference NonlinearOptimization.f90:1026 (fdd required)
-!Not provided (SURVEY.md sections 2, 8f): TrustRegion (MKL RCI), LagrangianMultiplier; AugmentedLagrangian is available in batched form from C / Python.
+!  NewtonRaphson     <- reference NonlinearOptimization.f90:1026 (without fdd: central differences of fd)
+!  AugmentedLagrangian <- reference NonlinearOptimization.f90:2005 (inner solvers LBFGS / ConjugateGradient / BFGS)
+!Not provided (SURVEY.md sections 2, 8f): TrustRegion (MKL RCI), LagrangianMultiplier.
 module NonlinearOptimization
     use iso_c_binding
     implicit none
@@ -74,6 +75,18 @@ module NonlinearOptimization
             integer(c_int),intent(in)::dim
             type(c_ptr),value::Strong,Warning,MaxIteration,Precision,MinStepLength,WolfeConst1,WolfeConst2,Increment
         end subroutine flc_newtonraphson
+        subroutine flc_augmentedlagrangian(f,fd,c,cd,x,N,M,UnconstrainedSolver,lambda0,miu0,fdd,cdd,ExactStep,Memory,&
+        Method,f_fd,Strong,Warning,MaxIteration,Precision,MinStepLength,WolfeConst1,WolfeConst2,Increment,&
+        len_UnconstrainedSolver,len_Method) bind(C,name='__nonlinearoptimization_MOD_augmentedlagrangian')
+            import
+            type(c_funptr),value::f,fd,c,cd,fdd,cdd,f_fd
+            real(c_double)::x(*)
+            integer(c_int),intent(in)::N,M
+            character(kind=c_char)::UnconstrainedSolver(*),Method(*)
+            type(c_ptr),value::lambda0,miu0,ExactStep,Memory
+            type(c_ptr),value::Strong,Warning,MaxIteration,Precision,MinStepLength,WolfeConst1,WolfeConst2,Increment
+            integer(c_int),value::len_UnconstrainedSolver,len_Method
+        end subroutine flc_augmentedlagrangian
         subroutine fl_default_options(opt,solver) bind(C,name='fl_default_options')
             import
             type(fl_options),intent(out)::opt
@@ -197,8 +210,8 @@ contains
         call flc_bfgs(c_funloc(f),c_funloc(fd),x,dim,pfdd,pe,pf_fd,p(1),p(2),p(3),p(4),p(5),p(6),p(7),p(8))
     end subroutine BFGS
 
-    !Newton-Raphson method (reference NonlinearOptimization.f90:1026); fdd (analytical Hessian) is required here:
-    !without it the reference calls MKL djacobi, which is not part of this build
+    !Newton-Raphson method (reference NonlinearOptimization.f90:1026); without fdd the Hessian comes from central
+    !differences of fd (the reference calls MKL djacobi there)
     subroutine NewtonRaphson(f, fd, x, dim, &
     fdd, &
     f_fd, Strong, Warning, MaxIteration, Precision, MinStepLength, WolfeConst1, WolfeConst2, Increment)
@@ -219,6 +232,54 @@ contains
         pfdd=c_null_funptr; if(present(fdd)) pfdd=c_funloc(fdd)
         call flc_newtonraphson(c_funloc(f),c_funloc(fd),x,dim,pfdd,pf_fd,p(1),p(2),p(3),p(4),p(5),p(6),p(7),p(8))
     end subroutine NewtonRaphson
+
+    !Augmented Lagrangian multiplier method (reference NonlinearOptimization.f90:2005-2241): equality constraints
+    !c(x)=0 with  subroutine c(c(x),x,M,N),  subroutine cd(c'(x),x,M,N) (c'(x) is N x M).  Inner solvers on the device:
+    !'LBFGS', 'ConjugateGradient', 'BFGS' (default, quasi-Newton branch); the wrappers L, Ld (2193-2228) are evaluated on
+    !the host next to the caller's f, fd, c, cd.  fdd / cdd are accepted for keyword compatibility and not used
+    subroutine AugmentedLagrangian(f, fd, c, cd, x, N, M, &
+    UnconstrainedSolver, lambda0, miu0, &
+    fdd, cdd, ExactStep, Memory, Method, &
+    f_fd, Strong, Warning, MaxIteration, Precision, MinStepLength, WolfeConst1, WolfeConst2, Increment)
+        external::f,fd,c,cd
+        integer,intent(in)::N,M
+        real*8,dimension(N),intent(inout)::x
+        character(*),intent(in),optional::UnconstrainedSolver
+        real*8,dimension(M),intent(in),optional,target::lambda0
+        integer,external,optional::f_fd,fdd,cdd
+        logical,intent(in),optional::Strong,Warning
+        integer,intent(in),optional::MaxIteration,ExactStep,Memory
+        real*8,intent(in),optional::miu0,Precision,MinStepLength,WolfeConst1,WolfeConst2,Increment
+        character(*),intent(in),optional::Method
+        integer(c_int32_t),target::ls(2)
+        integer(c_int),target::li(1),le,lm
+        real(c_double),target::lr(5),lmiu
+        type(c_ptr)::p(8),pe,pm,pl,pmiu
+        type(c_funptr)::pf_fd,pfdd,pcdd
+        character(kind=c_char)::sv(32),mt(2)
+        integer::i,lsv
+        sv=' '; lsv=4; sv(1)='B'; sv(2)='F'; sv(3)='G'; sv(4)='S'!default solver (reference NonlinearOptimization.f90:2041)
+        if(present(UnconstrainedSolver)) then
+            sv=' '; lsv=min(len(UnconstrainedSolver),32)
+            do i=1,lsv; sv(i)=UnconstrainedSolver(i:i); end do
+        end if
+        mt(1)='D'; mt(2)='Y'
+        if(present(Method)) then
+            mt=' '
+            if(len(Method)>=1) mt(1)=Method(1:1)
+            if(len(Method)>=2) mt(2)=Method(2:2)
+        end if
+        call pack_common(p,ls,li,lr,Strong,Warning,MaxIteration,Precision,MinStepLength,WolfeConst1,WolfeConst2,Increment)
+        pe=c_null_ptr; if(present(ExactStep)) then; le=ExactStep; pe=c_loc(le); end if
+        pm=c_null_ptr; if(present(Memory)) then; lm=Memory; pm=c_loc(lm); end if
+        pmiu=c_null_ptr; if(present(miu0)) then; lmiu=miu0; pmiu=c_loc(lmiu); end if
+        pl=c_null_ptr; if(present(lambda0)) pl=c_loc(lambda0)
+        pf_fd=c_null_funptr; if(present(f_fd)) pf_fd=c_funloc(f_fd)
+        pfdd=c_null_funptr; if(present(fdd)) pfdd=c_funloc(fdd)
+        pcdd=c_null_funptr; if(present(cdd)) pcdd=c_funloc(cdd)
+        call flc_augmentedlagrangian(c_funloc(f),c_funloc(fd),c_funloc(c),c_funloc(cd),x,N,M,sv,pl,pmiu,pfdd,pcdd,pe,pm,&
+            mt,pf_fd,p(1),p(2),p(3),p(4),p(5),p(6),p(7),p(8),int(lsv,c_int),2_c_int)
+    end subroutine AugmentedLagrangian
 
     subroutine pack_common(p,ls,li,lr,Strong,Warning,MaxIteration,Precision,MinStepLength,WolfeConst1,WolfeConst2,Increment)
         type(c_ptr),intent(out)::p(8)

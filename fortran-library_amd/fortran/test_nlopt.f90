@@ -47,6 +47,19 @@ contains
         end do
         fdd=0
     end function fdd
+    !unit-sphere equality constraint like the reference's test (test/test.f90:677-695)
+    subroutine c(cx,x,M,N)
+        integer,intent(in)::M,N
+        real*8,dimension(M),intent(out)::cx
+        real*8,dimension(N),intent(in)::x
+        cx(1)=dot_product(x,x)-1d0
+    end subroutine c
+    subroutine cd(cdx,x,M,N)
+        integer,intent(in)::M,N
+        real*8,dimension(N,M),intent(out)::cdx
+        real*8,dimension(N),intent(in)::x
+        cdx(:,1)=2d0*x
+    end subroutine cd
 end module quartic
 
 program main
@@ -74,6 +87,14 @@ program main
     write(*,*)'Newton'
     call start(); call NewtonRaphson(f,fd,x,dim,fdd=fdd,Warning=.false.); write(*,'(A,ES24.16)')' Newton ',norm2(x)
     call start(); call NewtonRaphson(f,fd,x,dim,fdd=fdd,f_fd=f_fd,Strong=.false.,Warning=.false.); write(*,'(A,ES24.16)')' Newton-f_fd-Wolfe ',norm2(x)
+    write(*,*)'Newton-Raphson / BFGS with numerical Hessian (no fdd)'
+    call start(); call NewtonRaphson(f,fd,x,dim,Warning=.false.); write(*,'(A,ES24.16)')' Newton-numH ',norm2(x)
+    call start(); call BFGS(f,fd,x,dim,Warning=.false.); write(*,'(A,ES24.16)')' BFGS-default-numH ',norm2(x)
+    write(*,*)'Augmented Lagrangian (unit sphere): | |x| - 1 |'
+    call start(); call AugmentedLagrangian(f,fd,c,cd,x,dim,1,UnconstrainedSolver='LBFGS',Warning=.false.,&
+        MaxIteration=100,Precision=1d-10); write(*,'(A,ES24.16)')' AugLag-LBFGS ',abs(norm2(x)-1d0)
+    call start(); call AugmentedLagrangian(f,fd,c,cd,x,dim,1,UnconstrainedSolver='ConjugateGradient',Method='PR',f_fd=f_fd,&
+        Warning=.false.,MaxIteration=100,Precision=1d-10); write(*,'(A,ES24.16)')' AugLag-CG-PR ',abs(norm2(x)-1d0)
     write(*,*)'Mission complete'
 contains
     subroutine start()

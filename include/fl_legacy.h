@@ -22,8 +22,9 @@
  * the reference's "unsupported unconstrained solver" message); the wrappers L, Ld, L_Ld that compose the
  * caller's f, fd, c, cd (NO.f90:2193-2228) run on the host next to those callbacks, every inner solve on the GPU.
  * NewtonRaphson and BFGS with ExactStep > 0 call the caller's fdd on the host and ship the Hessian to the GPU
- * (Cholesky solve / inverse there); without fdd the reference would call MKL djacobi -- not part of this build:
- * BFGS then runs quasi-Newton updates only, NewtonRaphson refuses (both say so on stdout).
+ * (Cholesky solve / inverse there); without fdd the reference calls MKL djacobi (closed, step rule unpublished):
+ * here central differences of the caller's fd, h = 1e-8 max(1,|x_j|), 2n gradient calls per Hessian -- same
+ * end points, not bit-identical ("parity unpinned" for this branch).
  * TrustRegion (MKL RCI) is not exported (out of scope).
  */
 #ifndef FL_LEGACY_H

@@ -92,7 +92,8 @@ void fl_default_options(fl_options *opt, int solver);
 
 /* Reduction geometry the kernels use for dimension n: `threads` per problem (one
  * workgroup), `ept` elements per thread.  Sums are taken per thread over its
- * elements, then a 64-lane xor butterfly, then waves left to right -- the order
+ * elements, then the fixed 64-lane tree of csrc/fl_reduce.hpp (lanes l and l+32,
+ * then l and l+16, then mirror steps inside a row of 16), then waves left to right -- the order
  * tests replay on the CPU to compare bit for bit.  FL_ERR_UNSUPPORTED_SIZE if n
  * is too large for the on-chip path. */
 int fl_reduction_geometry(int n, int *threads, int *ept);

@@ -22,7 +22,8 @@
  *                  dot_product intrinsic everywhere, e.g. NO.f90:442, 591).
  *   FLO_SUM_TREE : the same algorithm with every sum taken in the fixed
  *                  reduction order of the HIP kernels (thread-strided partials,
- *                  64-lane xor butterfly, waves left to right) so that the GPU
+ *                  the 64-lane tree of csrc/fl_reduce.hpp: halves, quarter rows,
+ *                  mirror steps inside a row; waves left to right) so that the GPU
  *                  result can be compared BIT FOR BIT.
  */
 #ifndef FL_ORACLE_H
