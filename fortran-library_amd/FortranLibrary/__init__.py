@@ -6,4 +6,5 @@ Mirrors the layout of the reference's ``FortranLibrary`` Python package
 ``FortranLibrary.NonlinearOptimization`` with the batched solvers.
 """
 from .basic import FL, library_path  # noqa: F401
+from .General import ShowTime, dScientificNotation  # noqa: F401
 from . import NonlinearOptimization  # noqa: F401

@@ -87,6 +87,15 @@ void nonlinearoptimization_mp_lbfgs_(fl_f_cb f, fl_fd_cb fd, double *x, const in
 void nonlinearoptimization_mp_bfgs_(fl_f_cb f, fl_fd_cb fd, double *x, const int *dim, fl_fdd_cb fdd,
                                     const int *ExactStep, fl_f_fd_cb f_fd, FL_LEGACY_COMMON_ARGS);
 
+/* Import-time symbols of the reference's Python package (FortranLibrary/General.py:4-16 probes
+ * general_mp_showtime_ / __general_MOD_showtime when the package is imported, so `CDLL('libFL.so')` users keep
+ * importing it against this library).  Host utilities, restated from source/General.f90:29-55:
+ * ShowTime prints " yyyy year mm month dd day hh:mm:ss"; dScientificNotation: x_in = x_out * 10^i, 1 <= x_out < 10. */
+void __general_MOD_showtime(void);
+void general_mp_showtime_(void);
+void __general_MOD_dscientificnotation(double *x, int *i);
+void general_mp_dscientificnotation_(double *x, int *i);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,6 +9,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -34,6 +35,15 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert len(lnames) == 14
     for nme in lnames:
         assert hasattr(lib, nme), nme
+    # import-time symbols of the reference's Python package (FortranLibrary/General.py:4-16)
+    for nme in ("__general_MOD_showtime", "general_mp_showtime_", "__general_MOD_dscientificnotation", "general_mp_dscientificnotation_"):
+        assert hasattr(lib, nme), nme
+    xv, iv = C.c_double(12345.678), C.c_int(7)
+    lib.__general_MOD_dscientificnotation(C.byref(xv), C.byref(iv))
+    assert iv.value == 4 and abs(xv.value - 1.2345678) < 1e-12
+    xv = C.c_double(0.00042)
+    lib.general_mp_dscientificnotation_(C.byref(xv), C.byref(iv))
+    assert iv.value == -4 and abs(xv.value - 4.2) < 1e-12
     t, e = C.c_int(), C.c_int()
     for n, (T, E) in {10: (64, 2), 256: (64, 4), 512: (128, 4), 1024: (128, 8), 2048: (256, 8), 4096: (512, 8)}.items():
         assert lib.fl_reduction_geometry(n, C.byref(t), C.byref(e)) == 0 and (t.value, e.value) == (T, E)
@@ -142,3 +152,18 @@ def test_strong_wolfe_quirk_path_is_exercised_and_matches():
             assert res[0] == res[1] and res[2] == res[3]
             differ += res[0][:2] != res[2][:2]
     assert differ > 50
+
+
+def test_reference_python_package_imports_against_this_library():
+    """Drop-in at the Python boundary: the reference's own ctypes package does CDLL('libFL.so') and
+    probes __general_MOD_showtime when imported (FortranLibrary/General.py:4-7).  With this build's lib directory on
+    the loader path it imports and its General functions work.  Only where the reference checkout is mounted."""
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "FortranLibrary")):
+        pytest.skip("reference checkout not mounted (GPU box)")
+    lib = os.path.join(ROOT, "fortran-library_amd", "lib")
+    env = dict(os.environ, PYTHONPATH=ref, LD_LIBRARY_PATH=lib + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    code = "import FortranLibrary as F; F.ShowTime(); print('SN', *F.dScientificNotation(1234.5))"
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env, cwd="/tmp")
+    assert out.returncode == 0, out.stderr
+    assert " year " in out.stdout and "SN 1.2345" in out.stdout and out.stdout.strip().endswith(" 3")
