@@ -274,7 +274,22 @@ def main():
         res["parity"] = {"final_f_rel_err_max": float(np.max(np.abs(gf - ref["f"]) / den)),
                          "minimiser_err_max": float(np.max(np.linalg.norm(gx - ref["x"], axis=1)
                                                            / np.maximum(1.0, np.linalg.norm(ref["x"], axis=1)))),
-                         "sample": S, "tolerance": {"f_rel": 1e-10, "x": 1e-8}}
+                         "sample": S, "tolerance": {"f_rel": 1e-10, "x": 1e-8},
+                         "minimiser_note": "reference-order CPU run and GPU run both stop at ||g|| < Precision = 1e-6; with "
+                                           "kappa up to 1e3 that defines the minimiser only to ~1e-6, the distance between "
+                                           "two valid stopping points.  The 1e-8 tolerance is checked at Precision 1e-9 in "
+                                           "tests/test_gpu_parity.py::test_north_star_tolerance_vs_reference_summation"}
+        # the same problems against the oracle in the kernels' summation order: every bit must agree
+        SB = min(S, 256)
+        T_, E_ = NLO.reduction_geometry(n)
+        tre = O.solve_batch(O.LBFGS, kind, xs[:SB], d=ds[:SB] if ds is not None else None,
+                            b=bs[:SB] if bs is not None else None, opts=oo, sum_mode=O.TREE, threads=T_, ept=E_,
+                            nthreads=cores)
+        res["parity"]["bit_exact_vs_oracle_kernel_order"] = {
+            "problems": SB,
+            "x": bool(np.array_equal(gx[:SB].view(np.uint64), tre["x"].view(np.uint64))),
+            "f": bool(np.array_equal(gf[:SB].view(np.uint64), tre["f"].view(np.uint64))),
+            "iterations": bool(np.array_equal(out["iters"][:SB].cpu().numpy(), tre["iters"]))}
         res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
 
     print(json.dumps(res))
