@@ -1,0 +1,548 @@
+// fl_big.hpp -- the solver machine for problems that do not fit the register path (n > 4096).
+//
+// Same algorithm, same request protocol and the same fixed summation order as Solver (fl_device.hpp), restated
+// over vectors that live in HBM: ONE workgroup of 1024 threads owns one problem; thread t handles the element
+// pairs (c*1024 + t)*2 + {0,1}, c = 0..nslot-1 -- the register path's layout with EPT = 2*nslot -- and sums its
+// terms in that order, then the 16 waves left to right, so the oracle replays it with threads = 1024,
+// ept = 2*nslot (fl_reduction_geometry reports both).  SteepestDescent (NO.f90:55-188), ConjugateGradient
+// (193-394), L-BFGS (398-625); the dense solvers (BFGS, NewtonRaphson) stay on the register path.
+// Every element is only ever touched by its own thread, so passes need no barrier besides the reductions --
+// except Rosenbrock's neighbour reads, which follow a __syncthreads() after x has been written.
+// The L-BFGS recursion is fused pass-wise: the axpy of step j and the dot product of step j+1 share one pass.
+#pragma once
+#include "fl_device.hpp"
+
+namespace fl {
+
+template <int OBJ, int METHOD> struct BigSolver {
+    static_assert(METHOD == FL_SOLVER_SD || METHOD == FL_SOLVER_CG || METHOD == FL_SOLVER_LBFGS,
+                  "vectors-in-HBM path: SD, CG, L-BFGS");
+    static constexpr int NW = 16, T = 1024;
+    static constexpr bool NEEDS_G0 = (METHOD != FL_SOLVER_SD);
+    static constexpr int ROWS = 4; // p, x0, g0, g per problem
+    // LDS carve (doubles)
+    static constexpr int L_RED = 0;
+    static constexpr int L_RHO = L_RED + 2 * Reducer<NW>::NVMAX * NW;
+    static constexpr int L_ALPHA = L_RHO + FL_MAX_MEMORY;
+    static constexpr int LDS_TOTAL = L_ALPHA + FL_MAX_MEMORY;
+    static constexpr int RCI_SCALARS = 48;
+
+    const SolveArgs &A;
+    double *lds;
+    int prob, n, nslot, tid;
+    size_t npad;
+    bool ual; // user rows (stride n) are 16-byte aligned
+    Reducer<NW> R;
+    double *x;
+    const double *dd, *bb;
+    double *p, *x0, *g0, *g, *hist;
+    // uniform scalars (names as in Solver)
+    double fnew, gg, pp, phid, phidold, a;
+    int iters, nf, ng, status, phase, pending;
+    int recent, cnt;
+    double yy_recent, rho_recent;
+    LineSearch ls;
+    enum { PH_INIT = 0, PH_LS = 1, PH_DONE = 2 };
+
+    __host__ __device__ static int slots_for(int n) { return ((n + 1) / 2 + T - 1) / T; }
+
+    __device__ __forceinline__ BigSolver(const SolveArgs &A_, double *lds_, double *rows_all)
+        : A(A_), lds(lds_), prob(blockIdx.x), n(A_.n), tid(threadIdx.x), R{lds_ + L_RED, 0}
+    {
+        nslot = slots_for(n);
+        npad = (size_t)nslot * T * 2;
+        ual = (n & 1) == 0;
+        x = A.x + (size_t)prob * n;
+        dd = A.d ? A.d + (size_t)prob * n : nullptr;
+        bb = A.b ? A.b + (size_t)prob * n : nullptr;
+        double *rows = rows_all + (size_t)prob * ROWS * npad;
+        p = rows;
+        x0 = rows + npad;
+        g0 = rows + 2 * npad;
+        g = rows + 3 * npad;
+        hist = (METHOD == FL_SOLVER_LBFGS) ? A.hist + (size_t)prob * (size_t)(2 * A.mem) * npad : nullptr;
+    }
+
+    // ---- element pairs
+    __device__ __forceinline__ int e_of(int c) const { return (c * T + tid) << 1; }
+    __device__ __forceinline__ void ldu(const double *row, int e, double &u, double &v) const
+    {
+        if (ual && e + 1 < n) {
+            const double2 t = *reinterpret_cast<const double2 *>(row + e);
+            u = t.x;
+            v = t.y;
+        } else {
+            u = (e < n) ? row[e] : 0.0;
+            v = (e + 1 < n) ? row[e + 1] : 0.0;
+        }
+    }
+    __device__ __forceinline__ void stu(double *row, int e, double u, double v) const
+    {
+        if (ual && e + 1 < n) {
+            *reinterpret_cast<double2 *>(row + e) = make_double2(u, v);
+        } else {
+            if (e < n) row[e] = u;
+            if (e + 1 < n) row[e + 1] = v;
+        }
+    }
+    __device__ __forceinline__ static void ldw(const double *row, int e, double &u, double &v)
+    {
+        const double2 t = *reinterpret_cast<const double2 *>(row + e);
+        u = t.x;
+        v = t.y;
+    }
+    __device__ __forceinline__ static void stw(double *row, int e, double u, double v)
+    {
+        *reinterpret_cast<double2 *>(row + e) = make_double2(u, v);
+    }
+    // running sum in the register path's order: first term of the thread starts it
+    __device__ __forceinline__ static void acc2(double &s, int c, double ta, double tb)
+    {
+        s = (c == 0) ? ta : s + ta;
+        s = s + tb;
+    }
+
+    // ---------------------------------------------------------------- setup
+    __device__ __forceinline__ void init()
+    {
+        iters = nf = ng = 0;
+        status = FL_STATUS_CONVERGED;
+        recent = -1;
+        cnt = 0;
+        yy_recent = rho_recent = 0.0;
+        fnew = gg = pp = phid = phidold = a = 0.0;
+        phase = PH_INIT;
+        pending = 0;
+    }
+    __device__ __forceinline__ void clear_rows() // first launch: p = 0 like the register path, padding defined
+    {
+        for (int c = 0; c < nslot; ++c) {
+            const int e = e_of(c);
+            stw(p, e, 0.0, 0.0);
+            stw(x0, e, 0.0, 0.0);
+            stw(g0, e, 0.0, 0.0);
+            stw(g, e, 0.0, 0.0);
+        }
+    }
+    __device__ __forceinline__ int start()
+    {
+        phase = PH_INIT;
+        pending = FL_REQ_F | FL_REQ_G | FL_REQ_NOMOVE;
+        return pending;
+    }
+
+    // ---------------------------------------------------------------- evaluation
+    __device__ __forceinline__ void move(double at)
+    {
+        for (int c = 0; c < nslot; ++c) {
+            const int e = e_of(c);
+            double xa, xb, pa, pb;
+            ldw(x0, e, xa, xb);
+            ldw(p, e, pa, pb);
+            stu(x, e, xa + at * pa, xb + at * pb);
+        }
+    }
+    // built-in objective at the x in the user array: f, g (stored), g.p, g.g
+    __device__ __forceinline__ void evaluate(double &f, double &gp, double &ggo)
+    {
+        if constexpr (OBJ == FL_OBJ_ROSENBROCK) __syncthreads(); // neighbours' x are written
+        double r[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int c = 0; c < nslot; ++c) {
+            const int e = e_of(c);
+            double xa, xb, ga, gb, ta, tb, ua = 0.0, ub = 0.0;
+            ldu(x, e, xa, xb);
+            if constexpr (OBJ == FL_OBJ_QUARTIC) { // test/test.f90:630-663
+                const double a3 = xa * xa * xa, b3 = xb * xb * xb;
+                ta = a3 * xa;
+                tb = b3 * xb;
+                ga = 4.0 * a3;
+                gb = 4.0 * b3;
+            } else if constexpr (OBJ == FL_OBJ_DIAGQUAD) {
+                double da, db, ba, bbv;
+                ldu(dd, e, da, db);
+                ldu(bb, e, ba, bbv);
+                const double dxa = da * xa, dxb = db * xb;
+                ta = dxa * xa;
+                tb = dxb * xb;
+                ua = ba * xa;
+                ub = bbv * xb;
+                ga = dxa - ba;
+                gb = dxb - bbv;
+            } else if constexpr (OBJ == FL_OBJ_ROSENBROCK) { // as Objective<FL_OBJ_ROSENBROCK>::eval
+                const double xl = (e >= 1 && e - 1 < n) ? x[e - 1] : 0.0;
+                const double xr = (e + 2 < n) ? x[e + 2] : 0.0;
+                const double ul = xa - xl * xl, um = xb - xa * xa, ur = xr - xb * xb;
+                const double va = 1.0 - xa, vb = 1.0 - xb;
+                const double A_a = (e >= 1) ? 200.0 * ul : 0.0;
+                const double A_b = 200.0 * um;
+                ta = tb = ga = gb = 0.0;
+                if (e <= n - 2) {
+                    ta = 100.0 * (um * um) + va * va;
+                    ga = A_a - 400.0 * xa * um - 2.0 * va;
+                } else if (e == n - 1) {
+                    ga = A_a;
+                }
+                if (e + 1 <= n - 2) {
+                    tb = 100.0 * (ur * ur) + vb * vb;
+                    gb = A_b - 400.0 * xb * ur - 2.0 * vb;
+                } else if (e + 1 == n - 1) {
+                    gb = A_b;
+                }
+            } else {
+                ta = tb = ga = gb = 0.0;
+            }
+            stw(g, e, ga, gb);
+            double pa, pb;
+            ldw(p, e, pa, pb);
+            acc2(r[0], c, ta, tb);
+            if constexpr (OBJ == FL_OBJ_DIAGQUAD) acc2(r[1], c, ua, ub);
+            acc2(r[2], c, ga * pa, gb * pb);
+            acc2(r[3], c, ga * ga, gb * gb);
+        }
+        R.run(r);
+        f = uni(Objective<OBJ, 1, 2>::combine(r[0], r[1]));
+        gp = uni(r[2]);
+        ggo = uni(r[3]);
+        if constexpr (OBJ == FL_OBJ_ROSENBROCK) __syncthreads(); // all neighbour reads done before x moves again
+    }
+    // reverse communication: the caller's gradient [n] -> g, with g.p and g.g
+    __device__ __forceinline__ void take_gradient(const double *g_user, double &gp, double &ggo)
+    {
+        double r[2] = {0.0, 0.0};
+        for (int c = 0; c < nslot; ++c) {
+            const int e = e_of(c);
+            double ga, gb, pa, pb;
+            ldu(g_user, e, ga, gb);
+            stw(g, e, ga, gb);
+            ldw(p, e, pa, pb);
+            acc2(r[0], c, ga * pa, gb * pb);
+            acc2(r[1], c, ga * ga, gb * gb);
+        }
+        R.run(r);
+        gp = uni(r[0]);
+        ggo = uni(r[1]);
+    }
+
+    // ---------------------------------------------------------------- machine (Solver::advance and friends)
+    __device__ __forceinline__ int advance(double fv, double pv, double gg_new)
+    {
+        nf += (pending & FL_REQ_F) ? 1 : 0;
+        ng += (pending & FL_REQ_G) ? 1 : 0;
+        int rq;
+        if (phase == PH_INIT) {
+            rq = after_init(fv, gg_new);
+        } else {
+            gg = gg_new;
+            rq = __builtin_amdgcn_readfirstlane(ls.step(fv, pv));
+            ls.uniformize();
+            if (rq == 0) rq = after_linesearch();
+        }
+        pending = rq;
+        return rq;
+    }
+    __device__ __forceinline__ double request_point() const { return ls.a_eval; }
+    __device__ __forceinline__ int max_linesearches() const
+    {
+        if constexpr (METHOD == FL_SOLVER_LBFGS) return A.mem + A.maxit;
+        return A.maxit;
+    }
+    __device__ __forceinline__ int finished()
+    {
+        phase = PH_DONE;
+        return 0;
+    }
+    __device__ __forceinline__ void neg_gradient_direction() // p=-fdnew
+    {
+        for (int c = 0; c < nslot; ++c) {
+            const int e = e_of(c);
+            double ga, gb;
+            ldw(g, e, ga, gb);
+            stw(p, e, -ga, -gb);
+        }
+    }
+    __device__ __forceinline__ int begin_linesearch()
+    {
+        int fused = A.fused;
+        if constexpr (METHOD == FL_SOLVER_LBFGS) fused = fused && (iters >= A.mem); // NO.f90:448-460, 486-498
+        for (int c = 0; c < nslot; ++c) { // xold=x; fdold=fdnew
+            const int e = e_of(c);
+            double u, v;
+            ldu(x, e, u, v);
+            stw(x0, e, u, v);
+            if constexpr (NEEDS_G0) {
+                ldw(g, e, u, v);
+                stw(g0, e, u, v);
+            }
+        }
+        phidold = phid;
+        const int strong = (METHOD == FL_SOLVER_CG && A.cg_method == FL_CG_PR) ? 1 : A.strong;
+        phase = PH_LS;
+        const int rq = __builtin_amdgcn_readfirstlane(ls.begin(strong, fused, A.c1, A.c2, A.incr, a, fnew, phid));
+        ls.uniformize();
+        return rq;
+    }
+    __device__ __forceinline__ int after_init(double f, double gg0)
+    {
+        fnew = f;
+        gg = gg0;
+        neg_gradient_direction();
+        phid = -gg;
+        pp = gg;
+        status = FL_STATUS_CONVERGED;
+        if (gg < A.tol) return finished();
+        a = uni((fnew == 0.0) ? 1.0 : fabs(fnew) / sqrt(gg));
+        status = FL_STATUS_MAXIT;
+        if (max_linesearches() <= 0) return finished();
+        return begin_linesearch();
+    }
+    __device__ __forceinline__ int after_linesearch()
+    {
+        a = ls.a;
+        fnew = ls.fx;
+        ++iters;
+        if (gg < A.tol) {
+            status = FL_STATUS_CONVERGED;
+            return finished();
+        }
+        if (pp * a * a < A.minstep) {
+            status = FL_STATUS_STEP_CONVERGED;
+            return finished();
+        }
+        if (iters >= max_linesearches()) {
+            status = FL_STATUS_MAXIT;
+            return finished();
+        }
+        if constexpr (METHOD == FL_SOLVER_SD) { // NO.f90:185-186
+            neg_gradient_direction();
+            phid = -gg;
+            pp = gg;
+            a = a * phidold / phid;
+        } else if constexpr (METHOD == FL_SOLVER_CG) {
+            direction_cg();
+        } else {
+            direction_lbfgs();
+        }
+        phid = uni(phid);
+        pp = uni(pp);
+        a = uni(a);
+        return begin_linesearch();
+    }
+
+    // ---------------------------------------------------------------- directions
+    __device__ __forceinline__ void direction_cg()
+    {
+        double beta;
+        if (A.cg_method == FL_CG_DY) { // NO.f90:366
+            double q[1] = {0.0};
+            for (int c = 0; c < nslot; ++c) {
+                const int e = e_of(c);
+                double ga, gb, oa, ob, pa, pb;
+                ldw(g, e, ga, gb);
+                ldw(g0, e, oa, ob);
+                ldw(p, e, pa, pb);
+                acc2(q[0], c, (ga - oa) * pa, (gb - ob) * pb);
+            }
+            R.run(q);
+            beta = gg / q[0];
+        } else { // NO.f90:387
+            double q[2] = {0.0, 0.0};
+            for (int c = 0; c < nslot; ++c) {
+                const int e = e_of(c);
+                double ga, gb, oa, ob;
+                ldw(g, e, ga, gb);
+                ldw(g0, e, oa, ob);
+                acc2(q[0], c, ga * (ga - oa), gb * (gb - ob));
+                acc2(q[1], c, oa * oa, ob * ob);
+            }
+            R.run(q);
+            beta = q[0] / q[1];
+        }
+        double q2[2] = {0.0, 0.0};
+        for (int c = 0; c < nslot; ++c) {
+            const int e = e_of(c);
+            double ga, gb, pa, pb;
+            ldw(g, e, ga, gb);
+            ldw(p, e, pa, pb);
+            pa = -ga + beta * pa;
+            pb = -gb + beta * pb;
+            stw(p, e, pa, pb);
+            acc2(q2[0], c, ga * pa, gb * pb);
+            acc2(q2[1], c, pa * pa, pb * pb);
+        }
+        R.run(q2);
+        phid = q2[0];
+        pp = q2[1];
+        if (phid > 0.0) { // NO.f90:368-370
+            neg_gradient_direction();
+            phid = -gg;
+            pp = gg;
+        }
+        a = a * phidold / phid;
+    }
+
+    __device__ __forceinline__ void direction_lbfgs()
+    {
+        double *rho_s = lds + L_RHO, *alpha_s = lds + L_ALPHA;
+        const int mem = A.mem;
+        recent = (recent + 1 == mem) ? 0 : recent + 1;
+        if (cnt < mem) ++cnt;
+        auto slot_of = [&](int j) {
+            int s = recent - j;
+            return s < 0 ? s + mem : s;
+        };
+        auto srow = [&](int j) { return hist + (size_t)(2 * slot_of(j)) * npad; };
+        // After() (NO.f90:609-624) with the first dot product of Before() riding along: p starts as g
+        double r[3] = {0.0, 0.0, 0.0};
+        {
+            double *s0 = srow(0), *y0 = s0 + npad;
+            for (int c = 0; c < nslot; ++c) {
+                const int e = e_of(c);
+                double xa, xb, oa, ob, ga, gb, ha, hb;
+                ldu(x, e, xa, xb);
+                ldw(x0, e, oa, ob);
+                ldw(g, e, ga, gb);
+                ldw(g0, e, ha, hb);
+                const double sa = xa - oa, sb = xb - ob, ya = ga - ha, yb = gb - hb;
+                stw(s0, e, sa, sb);
+                stw(y0, e, ya, yb);
+                acc2(r[0], c, ya * sa, yb * sb);
+                acc2(r[1], c, ya * ya, yb * yb);
+                acc2(r[2], c, sa * ga, sb * gb);
+            }
+        }
+        R.run(r);
+        if (tid == 0) rho_s[recent] = 1.0 / r[0];
+        rho_recent = uni(1.0 / r[0]);
+        yy_recent = uni(r[1]);
+        // Before() (NO.f90:586-608): newest -> oldest
+        double al = rho_recent * r[2];
+        if (tid == 0) alpha_s[recent] = al;
+        for (int j = 0; j < cnt; ++j) { // p = p - alpha_j y_j, next dot product in the same pass
+            const double *yj = srow(j) + npad;
+            const bool last = (j + 1 == cnt);
+            const double *nxt = last ? yj : srow(j + 1); // last: the first dot of the way up is y_{cnt-1}.p
+            const double *src = (j == 0) ? g : p;
+            double q[1] = {0.0};
+            for (int c = 0; c < nslot; ++c) {
+                const int e = e_of(c);
+                double pa, pb, ya, yb, na, nb;
+                ldw(src, e, pa, pb);
+                ldw(yj, e, ya, yb);
+                pa = pa - al * ya;
+                pb = pb - al * yb;
+                if (last) { // p=p/rho(recent)/(y.y)
+                    pa = pa / rho_recent / yy_recent;
+                    pb = pb / rho_recent / yy_recent;
+                    na = ya;
+                    nb = yb;
+                } else {
+                    ldw(nxt, e, na, nb);
+                }
+                stw(p, e, pa, pb);
+                acc2(q[0], c, na * pa, nb * pb);
+            }
+            R.run(q);
+            if (!last) {
+                const int sl = slot_of(j + 1);
+                al = rho_s[sl] * q[0];
+                if (tid == 0) alpha_s[sl] = al;
+            } else {
+                al = q[0]; // carries y_{cnt-1}.p into the way up
+            }
+        }
+        __syncthreads(); // alpha_s complete
+        double ydotp = al;
+        double rr[2] = {0.0, 0.0};
+        for (int j = cnt - 1; j >= 0; --j) { // p = p + (alpha_j - rho_j y_j.p) s_j
+            const int sl = slot_of(j);
+            const double co = alpha_s[sl] - rho_s[sl] * ydotp;
+            const double *sj = srow(j);
+            const bool last = (j == 0);
+            const double *nxt = last ? g : srow(j - 1) + npad;
+            double q[1] = {0.0};
+            rr[0] = rr[1] = 0.0;
+            for (int c = 0; c < nslot; ++c) {
+                const int e = e_of(c);
+                double pa, pb, sa, sb, na, nb;
+                ldw(p, e, pa, pb);
+                ldw(sj, e, sa, sb);
+                ldw(nxt, e, na, nb);
+                pa = pa + co * sa;
+                pb = pb + co * sb;
+                if (last) { // p=-p; phidnew=dot_product(fdnew,p)
+                    pa = -pa;
+                    pb = -pb;
+                    acc2(rr[0], c, na * pa, nb * pb);
+                    acc2(rr[1], c, pa * pa, pb * pb);
+                } else {
+                    acc2(q[0], c, na * pa, nb * pb);
+                }
+                stw(p, e, pa, pb);
+            }
+            if (last) {
+                R.run(rr);
+            } else {
+                R.run(q);
+                ydotp = q[0];
+            }
+        }
+        phid = rr[0];
+        pp = rr[1];
+        a = 1.0;
+    }
+
+    // ---------------------------------------------------------------- reverse communication: park / resume
+    __device__ __forceinline__ void save(double *sc, double *rho, double fv_c, double pv_c)
+    {
+        if constexpr (METHOD == FL_SOLVER_LBFGS) {
+            __syncthreads();
+            if (tid < FL_MAX_MEMORY) rho[tid] = lds[L_RHO + tid];
+        }
+        if (tid == 0) {
+            double *q = sc;
+            *q++ = fnew; *q++ = gg; *q++ = pp; *q++ = phid; *q++ = phidold; *q++ = a;
+            *q++ = yy_recent; *q++ = rho_recent; *q++ = fv_c; *q++ = pv_c;
+            *q++ = ls.c1; *q++ = ls.c2abs; *q++ = ls.incr; *q++ = ls.fx0; *q++ = ls.phid0;
+            *q++ = ls.a; *q++ = ls.aold; *q++ = ls.fx; *q++ = ls.fold; *q++ = ls.phidnew; *q++ = ls.phidold;
+            *q++ = ls.low; *q++ = ls.up; *q++ = ls.flow; *q++ = ls.fup; *q++ = ls.phidlow; *q++ = ls.phidup;
+            *q++ = ls.plma; *q++ = ls.a_eval;
+            int *iq = reinterpret_cast<int *>(sc + 32);
+            *iq++ = iters; *iq++ = nf; *iq++ = ng; *iq++ = status; *iq++ = phase; *iq++ = pending;
+            *iq++ = recent; *iq++ = cnt; *iq++ = ls.st; *iq++ = ls.zret; *iq++ = ls.fused;
+        }
+    }
+    __device__ __forceinline__ void load(const double *sc, const double *rho, double &fv_c, double &pv_c)
+    {
+        if constexpr (METHOD == FL_SOLVER_LBFGS) {
+            if (tid < FL_MAX_MEMORY) lds[L_RHO + tid] = rho[tid];
+            __syncthreads();
+        }
+        const double *q = sc;
+        fnew = *q++; gg = *q++; pp = *q++; phid = *q++; phidold = *q++; a = *q++;
+        yy_recent = *q++; rho_recent = *q++; fv_c = *q++; pv_c = *q++;
+        ls.c1 = *q++; ls.c2abs = *q++; ls.incr = *q++; ls.fx0 = *q++; ls.phid0 = *q++;
+        ls.a = *q++; ls.aold = *q++; ls.fx = *q++; ls.fold = *q++; ls.phidnew = *q++; ls.phidold = *q++;
+        ls.low = *q++; ls.up = *q++; ls.flow = *q++; ls.fup = *q++; ls.phidlow = *q++; ls.phidup = *q++;
+        ls.plma = *q++; ls.a_eval = *q++;
+        const int *iq = reinterpret_cast<const int *>(sc + 32);
+        iters = *iq++; nf = *iq++; ng = *iq++; status = *iq++; phase = *iq++; pending = *iq++;
+        recent = *iq++; cnt = *iq++; ls.st = *iq++; ls.zret = *iq++; ls.fused = *iq++;
+        // every wave has read the parked scalars before thread 0 may overwrite them in save(): a step that only
+        // takes an objective value has no other barrier
+        __syncthreads();
+    }
+
+    __device__ __forceinline__ void finish() // x already holds the last evaluated point
+    {
+        if (tid == 0) {
+            if (A.f_out) A.f_out[prob] = fnew;
+            if (A.gg_out) A.gg_out[prob] = gg;
+            if (A.iters) A.iters[prob] = iters;
+            if (A.status) A.status[prob] = status;
+            if (A.nf) A.nf[prob] = nf;
+            if (A.ng) A.ng[prob] = ng;
+        }
+    }
+};
+
+} // namespace fl

@@ -1081,6 +1081,9 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
         iters = *iq++; nf = *iq++; ng = *iq++; status = *iq++; phase = *iq++; pending = *iq++;
         recent = *iq++; cnt = *iq++; ls.st = *iq++; ls.zret = *iq++; ls.fused = *iq++;
         main_it = *iq++; h_valid = *iq++; hess_stage = *iq++;
+        // every wave has read the parked scalars before thread 0 may overwrite them in save(): a step that only
+        // takes an objective value has no other barrier
+        __syncthreads();
     }
 
     // ---------------------------------------------------------------- outputs

@@ -15,6 +15,7 @@
 // manglings): steepestdescent, conjugategradient(_basic), lbfgs, bfgs -- batch of one,
 // callbacks evaluated on the host, x copied device <-> host per evaluation.
 #include "fl_device.hpp"
+#include "fl_big.hpp"
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -69,6 +70,41 @@ __global__ __launch_bounds__(NW * 64) void rci_step_kernel(SolveArgs A, int firs
     if (threadIdx.x == 0) request[prob] = rq;
 }
 
+// n > 4096 (fl_big.hpp): the same step with the machine's vectors in HBM, one workgroup of 1024 threads per problem
+template <int METHOD>
+__global__ __launch_bounds__(1024) void rci_step_big_kernel(SolveArgs A, int first, double *sc_all, double *vec_all,
+                                                            double *rho_all, const double *f_dev, const double *g_dev,
+                                                            int32_t *request)
+{
+    using S = BigSolver<FL_OBJ_EXTERNAL, METHOD>;
+    __shared__ __attribute__((aligned(16))) double lds[S::LDS_TOTAL];
+    S s(A, lds, vec_all);
+    const int prob = blockIdx.x, n = A.n;
+    double *sc = sc_all + (size_t)prob * S::RCI_SCALARS;
+    double *rho = rho_all + (size_t)prob * FL_MAX_MEMORY;
+    s.init();
+    int rq;
+    double fv = 0.0, pv = 0.0;
+    if (first) {
+        s.clear_rows();
+        rq = s.start();
+    } else {
+        s.load(sc, rho, fv, pv);
+        if (s.phase == S::PH_DONE) {
+            if (threadIdx.x == 0) request[prob] = 0;
+            return;
+        }
+        double ggv = s.gg;
+        if (s.pending & FL_REQ_F) fv = f_dev[prob];
+        if (s.pending & FL_REQ_G) s.take_gradient(g_dev + (size_t)prob * n, pv, ggv);
+        rq = s.advance(fv, pv, ggv);
+    }
+    if (rq == 0) s.finish();
+    else if (!(rq & (FL_REQ_SAME | FL_REQ_NOMOVE))) s.move(s.request_point());
+    s.save(sc, rho, fv, pv);
+    if (threadIdx.x == 0) request[prob] = rq;
+}
+
 struct Rci {
     int solver, batch, n, nw, ept, first;
     SolveArgs A;
@@ -88,6 +124,20 @@ template <int NW, int EPT> static void launch_rci(Rci *h, const double *f, const
     case FL_SOLVER_CG: FL_RCI(FL_SOLVER_CG); break;
     case FL_SOLVER_BFGS: FL_RCI(FL_SOLVER_BFGS); break;
     case FL_SOLVER_NEWTON: FL_RCI(FL_SOLVER_NEWTON); break;
+    default: FL_RCI(FL_SOLVER_LBFGS); break;
+    }
+#undef FL_RCI
+}
+
+static void launch_rci_big(Rci *h, const double *f, const double *g, int32_t *req)
+{
+    dim3 grid(h->batch), block(1024);
+#define FL_RCI(M)                                                                                                 \
+    hipLaunchKernelGGL((rci_step_big_kernel<M>), grid, block, 0, h->stream, h->A, h->first, h->sc, h->vec, h->rho, f, \
+                       g, req)
+    switch (h->solver) {
+    case FL_SOLVER_SD: FL_RCI(FL_SOLVER_SD); break;
+    case FL_SOLVER_CG: FL_RCI(FL_SOLVER_CG); break;
     default: FL_RCI(FL_SOLVER_LBFGS); break;
     }
 #undef FL_RCI
@@ -119,6 +169,8 @@ int fl_rci_create(fl_rci **out, int solver, int batch, int n, const fl_options *
     if (opt->cg_method != FL_CG_DY && opt->cg_method != FL_CG_PR) return FL_ERR_INVALID_ARGUMENT;
     int threads = 0, ept = 0;
     if (fl_reduction_geometry(n, &threads, &ept) != FL_OK) return FL_ERR_UNSUPPORTED_SIZE;
+    // beyond the register path (1024 threads): SD / CG / L-BFGS only, the dense solvers need n <= 4096
+    if (threads == 1024 && (solver == FL_SOLVER_BFGS || solver == FL_SOLVER_NEWTON)) return FL_ERR_UNSUPPORTED_SIZE;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FL_ERR_NO_DEVICE;
     fl_rci *h = new (std::nothrow) fl_rci();
@@ -192,7 +244,8 @@ int fl_rci_step(fl_rci *h, double *x_dev, const double *f_dev, const double *g_d
     fl::Rci *r = &h->r;
     r->A.x = x_dev;
     const int nw = r->nw, ept = r->ept;
-    if (nw == 1 && ept == 2) fl::launch_rci<1, 2>(r, f_dev, g_dev, request_dev);
+    if (nw == 16) fl::launch_rci_big(r, f_dev, g_dev, request_dev);
+    else if (nw == 1 && ept == 2) fl::launch_rci<1, 2>(r, f_dev, g_dev, request_dev);
     else if (nw == 1 && ept == 4) fl::launch_rci<1, 4>(r, f_dev, g_dev, request_dev);
     else if (nw == 2 && ept == 4) fl::launch_rci<2, 4>(r, f_dev, g_dev, request_dev);
     else if (nw == 2 && ept == 8) fl::launch_rci<2, 8>(r, f_dev, g_dev, request_dev);

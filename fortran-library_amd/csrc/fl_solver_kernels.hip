@@ -11,6 +11,7 @@
 //     problem and the hardware dispatcher back-fills CUs as workgroups retire (no
 //     lock-step batch, no host round trips).
 #include "fl_device.hpp"
+#include "fl_big.hpp"
 
 #ifdef FL_MIN_WPE
 #define FL_OCC_ATTR __attribute__((amdgpu_waves_per_eu(FL_MIN_WPE)))
@@ -52,10 +53,57 @@ __global__ __launch_bounds__(NW * 64) FL_OCC_ATTR void fl_solve_kernel(SolveArgs
     s.finish();
 }
 
+// n > 4096: vectors in HBM, one workgroup of 1024 threads per problem (fl_big.hpp)
+template <int OBJ, int METHOD> __global__ __launch_bounds__(1024) void fl_big_solve_kernel(SolveArgs A, double *rows)
+{
+    using S = BigSolver<OBJ, METHOD>;
+    __shared__ __attribute__((aligned(16))) double lds[S::LDS_TOTAL];
+    S s(A, lds, rows);
+    s.init();
+    s.clear_rows();
+    int rq = s.start();
+    double fv = 0.0, pv = 0.0, gg = 0.0;
+    while (rq) {
+        if (!(rq & FL_REQ_SAME)) {
+            if (!(rq & FL_REQ_NOMOVE)) s.move(s.request_point());
+            s.evaluate(fv, pv, gg);
+        }
+        rq = s.advance(fv, pv, gg);
+    }
+    s.finish();
+}
+template <int OBJ> static hipError_t launch_big_m(int method, const SolveArgs &A, double *rows, hipStream_t st)
+{
+#define FL_BIG(M) hipLaunchKernelGGL((fl_big_solve_kernel<OBJ, M>), dim3(A.batch), dim3(1024), 0, st, A, rows)
+    switch (method) {
+    case FL_SOLVER_SD: FL_BIG(FL_SOLVER_SD); break;
+    case FL_SOLVER_CG: FL_BIG(FL_SOLVER_CG); break;
+    default: FL_BIG(FL_SOLVER_LBFGS); break;
+    }
+#undef FL_BIG
+    return hipGetLastError();
+}
+static hipError_t launch_big(int obj, int method, const SolveArgs &A, double *rows, hipStream_t st)
+{
+    switch (obj) {
+    case FL_OBJ_QUARTIC: return launch_big_m<FL_OBJ_QUARTIC>(method, A, rows, st);
+    case FL_OBJ_ROSENBROCK: return launch_big_m<FL_OBJ_ROSENBROCK>(method, A, rows, st);
+    default: return launch_big_m<FL_OBJ_DIAGQUAD>(method, A, rows, st);
+    }
+}
+
 // ------------------------------------------------------------ host dispatch
 struct GeoSel {
     int nw, ept;
 };
+static constexpr int FL_BIG_MAX_N = 1 << 27;
+// n beyond the register path: 1024 threads, 2*ceil(ceil(n/2)/1024) element slots per thread (fl_big.hpp)
+static bool select_big_geometry(int n, GeoSel &g)
+{
+    if (n <= 4096 || n > FL_BIG_MAX_N) return false;
+    g = {16, 2 * BigSolver<FL_OBJ_QUARTIC, FL_SOLVER_SD>::slots_for(n)};
+    return true;
+}
 static bool select_geometry(int n, GeoSel &g)
 {
     if (n <= 0) return false;
@@ -134,7 +182,14 @@ static int solve(int method, int objective, int batch, int n, double *x, const d
     if (objective == FL_OBJ_DIAGQUAD && (!d || !b)) return FL_ERR_INVALID_ARGUMENT;
     if (opt->cg_method != FL_CG_DY && opt->cg_method != FL_CG_PR) return FL_ERR_INVALID_ARGUMENT;
     GeoSel g;
-    if (!select_geometry(n, g)) return FL_ERR_UNSUPPORTED_SIZE;
+    bool big = false;
+    if (!select_geometry(n, g)) {
+        // beyond the register path: SD / CG / L-BFGS continue with vectors in HBM; the dense solvers and the
+        // augmented Lagrangian do not
+        if (aug || (method != FL_SOLVER_SD && method != FL_SOLVER_CG && method != FL_SOLVER_LBFGS)) return FL_ERR_UNSUPPORTED_SIZE;
+        if (!select_big_geometry(n, g)) return FL_ERR_UNSUPPORTED_SIZE;
+        big = true;
+    }
     SolveArgs A;
     A.n = n;
     A.batch = batch;
@@ -187,7 +242,22 @@ static int solve(int method, int objective, int batch, int n, double *x, const d
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FL_ERR_NO_DEVICE;
-    hipError_t e = launch(g, objective, method, aug != nullptr, A, static_cast<hipStream_t>(stream));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (big) {
+        // workspace: [hist: batch*2*mem rows][p, x0, g0, g: batch*4 rows], rows of npad doubles; SD / CG have no
+        // workspace argument in the C ABI: their four rows come from the stream-ordered allocator
+        const size_t npad = (size_t)g.nw * 64 * g.ept, rows_bytes = (size_t)batch * 4 * npad * sizeof(double);
+        double *rows = nullptr;
+        if (method == FL_SOLVER_LBFGS) {
+            rows = static_cast<double *>(ws) + (size_t)batch * 2 * (size_t)A.mem * npad;
+        } else if (hipMallocAsync((void **)&rows, rows_bytes, st) != hipSuccess) {
+            return FL_ERR_WORKSPACE;
+        }
+        hipError_t e = launch_big(objective, method, A, rows, st);
+        if (method != FL_SOLVER_LBFGS) (void)hipFreeAsync(rows, st);
+        return e == hipSuccess ? FL_OK : FL_ERR_NO_DEVICE;
+    }
+    hipError_t e = launch(g, objective, method, aug != nullptr, A, st);
     return e == hipSuccess ? FL_OK : FL_ERR_NO_DEVICE;
 }
 
@@ -234,7 +304,7 @@ int fl_newton_raphson_batched(int objective, int batch, int n, double *x_dev, co
 int fl_reduction_geometry(int n, int *threads, int *ept)
 {
     fl::GeoSel g;
-    if (!fl::select_geometry(n, g)) return FL_ERR_UNSUPPORTED_SIZE;
+    if (!fl::select_geometry(n, g) && !fl::select_big_geometry(n, g)) return FL_ERR_UNSUPPORTED_SIZE;
     if (threads) *threads = g.nw * 64;
     if (ept) *ept = g.ept;
     return FL_OK;
@@ -243,7 +313,12 @@ int fl_reduction_geometry(int n, int *threads, int *ept)
 size_t fl_workspace_bytes(int solver, int batch, int n, int memory)
 {
     fl::GeoSel g;
-    if (batch <= 0 || !fl::select_geometry(n, g)) return 0;
+    if (batch <= 0) return 0;
+    if (!fl::select_geometry(n, g)) { // vectors-in-HBM path: the ring plus the four vector rows (L-BFGS only)
+        if (solver != FL_SOLVER_LBFGS || !fl::select_big_geometry(n, g)) return 0;
+        const size_t mem = memory > 1 ? (size_t)memory : 1;
+        return (size_t)batch * (2 * mem + 4) * ((size_t)g.nw * 64 * g.ept) * sizeof(double);
+    }
     const size_t npad = (size_t)(g.nw * 64 * g.ept);
     if (solver == FL_SOLVER_LBFGS) {
         const size_t mem = memory > 1 ? (size_t)memory : 1;

@@ -98,6 +98,36 @@ def test_legacy_lbfgs_and_cg_host_callbacks_bitexact(with_ffd):
         assert cnt["f"] + cnt["f_fd"] == ref["nf"][0] and cnt["fd"] + cnt["f_fd"] == ref["ng"][0]
 
 
+def test_legacy_entry_points_beyond_the_register_path_n5001():
+    """The reference's routines take any dim; beyond n = 4096 the machine's vectors live in HBM (csrc/fl_big.hpp,
+    rci_step_big_kernel).  Host callbacks, odd n: equal to the oracle bit for bit, callback counts included."""
+    FL = _fl()
+    n = 5001
+    rng = np.random.default_rng(5)
+    x0 = 1.0 + 0.1 * rng.uniform(-1, 1, n)
+    f, fd, ffd, cnt, (T, E), _ = _callbacks(O.ROSENBROCK, n)
+    assert T == 1024
+    dim = C.c_int(n)
+    dp = C.POINTER(C.c_double)
+    x = x0.copy()
+    vals, refs = _common(maxit=25, precision=1e-9)
+    mem = C.c_int(5)
+    FL.__nonlinearoptimization_MOD_lbfgs(f, fd, x.ctypes.data_as(dp), C.byref(dim), C.byref(mem), ffd, *refs)
+    ref = O.solve_batch(O.LBFGS, O.ROSENBROCK, x0, opts=O.defaults(maxit=25, precision=1e-9, memory=5), use_ffd=True,
+                        sum_mode=O.TREE, threads=T, ept=E)
+    assert np.array_equal(x, ref["x"][0])
+    assert cnt["f"] + cnt["f_fd"] == ref["nf"][0] and cnt["fd"] + cnt["f_fd"] == ref["ng"][0]
+    for k in cnt:
+        cnt[k] = 0
+    x = x0.copy()
+    vals, refs = _common(maxit=25, precision=1e-9, c2=0.45)
+    FL.__nonlinearoptimization_MOD_conjugategradient_basic(f, fd, x.ctypes.data_as(dp), C.byref(dim), b"DY", *refs, C.c_int(2))
+    ref = O.solve_batch(O.CG, O.ROSENBROCK, x0, opts=O.defaults(maxit=25, precision=1e-9, c2=0.45), sum_mode=O.TREE,
+                        threads=T, ept=E)
+    assert np.array_equal(x, ref["x"][0])
+    assert cnt["f"] == ref["nf"][0] and cnt["fd"] == ref["ng"][0]
+
+
 def test_legacy_test_cpp_sequence_quartic_dim10():
     """the calls of the reference's test/test.cpp:84-125 that are on this path: SteepestDescent,
     ConjugateGradient (basic and with f_fd), BFGS -- quartic, dim 10; criterion 'close to 0'"""

@@ -186,11 +186,33 @@ def test_already_converged_start_and_status_codes():
     assert g["status"][0] == O.MAXIT and g["iters"][0] == 50 + 10
 
 
+@pytest.mark.parametrize("solver,kw", [(O.LBFGS, {}), (O.LBFGS, {"f_fd": True, "Memory": 4}), (O.LBFGS, {"Strong": False}),
+                                       (O.CG, {}), (O.CG, {"Method": "PR"}), (O.SD, {"MaxIteration": 40})])
+@pytest.mark.parametrize("kind,n", [(O.ROSENBROCK, 4097), (O.DIAGQUAD, 5000), (O.QUARTIC, 6145), (O.ROSENBROCK, 10000)])
+def test_beyond_the_register_path_vectors_in_hbm_bitexact(solver, kw, kind, n):
+    """n > 4096: one workgroup of 1024 threads per problem with its vectors in HBM (csrc/fl_big.hpp); the same
+    algorithm in the same summation order (threads = 1024, ept = 2*ceil(ceil(n/2)/1024)), odd n included."""
+    NLO = _nlo()
+    T, E = NLO.reduction_geometry(n)
+    assert T == 1024 and E == 2 * -(-((n + 1) // 2) // 1024)
+    rng = np.random.default_rng(n)
+    if kind == O.DIAGQUAD:
+        d, b = _quads(3, n, 10.0, 300.0, n)
+        x0 = np.zeros((3, n))
+    else:
+        d = b = None
+        x0 = (1.0 + 0.1 * rng.uniform(-1, 1, (3, n))) if kind == O.ROSENBROCK else rng.uniform(0.2, 1.0, (3, n))
+    kw = dict(kw)
+    kw.setdefault("MaxIteration", 60)
+    g, o = _both(solver, kind, x0, d, b, Precision=1e-9, **kw)
+    _assert_bitexact(g, o)
+
+
 def test_argument_errors_and_no_cpu_fallback():
     NLO = _nlo()
     x = torch.zeros(2, 5000, dtype=torch.float64, device="cuda:0")
-    with pytest.raises(NLO.FLError):  # n beyond the on-chip path
-        NLO.LBFGS(O.ROSENBROCK, x)
+    with pytest.raises(NLO.FLError):  # the dense solvers stay on the register path: n <= 4096
+        NLO.BFGS(O.ROSENBROCK, x, ExactStep=0)
     x = torch.zeros(2, 16, dtype=torch.float64, device="cuda:0")
     with pytest.raises(NLO.FLError):  # quadratic data missing
         NLO.LBFGS(O.DIAGQUAD, x)

@@ -47,9 +47,13 @@ def test_c_abi_library_exports_every_declared_symbol():
     t, e = C.c_int(), C.c_int()
     for n, (T, E) in {10: (64, 2), 256: (64, 4), 512: (128, 4), 1024: (128, 8), 2048: (256, 8), 4096: (512, 8)}.items():
         assert lib.fl_reduction_geometry(n, C.byref(t), C.byref(e)) == 0 and (t.value, e.value) == (T, E)
-    assert lib.fl_reduction_geometry(100000, C.byref(t), C.byref(e)) == -2
+    # beyond the register path: 1024 threads, 2*ceil(ceil(n/2)/1024) slots per thread (csrc/fl_big.hpp)
+    assert lib.fl_reduction_geometry(100000, C.byref(t), C.byref(e)) == 0 and (t.value, e.value) == (1024, 98)
+    assert lib.fl_reduction_geometry(4097, C.byref(t), C.byref(e)) == 0 and (t.value, e.value) == (1024, 6)
+    assert lib.fl_reduction_geometry((1 << 27) + 1, C.byref(t), C.byref(e)) == -2
     lib.fl_workspace_bytes.restype = C.c_size_t
     assert lib.fl_workspace_bytes(2, 65536, 1024, 10) == 65536 * 20 * 1024 * 8
+    assert lib.fl_workspace_bytes(2, 3, 5000, 10) == 3 * (20 + 4) * 6144 * 8  # ring + the four vector rows
 
 
 def _driver():
