@@ -39,7 +39,8 @@ extern "C" {
 
 #define FL_OK 0
 #define FL_ERR_INVALID_ARGUMENT (-1) /* NULL pointer, batch/n <= 0, unknown enum */
-#define FL_ERR_UNSUPPORTED_SIZE (-2) /* n or memory beyond what the kernels hold on chip */
+#define FL_ERR_UNSUPPORTED_SIZE (-2) /* Memory > FL_MAX_MEMORY; n > 4096 for the dense solvers (BFGS, NewtonRaphson) */
+                                     /* and the augmented Lagrangian; n > 2^27 for SD / CG / L-BFGS                  */
 #define FL_ERR_WORKSPACE (-3)        /* workspace missing or too small */
 #define FL_ERR_NO_DEVICE (-4)        /* no HIP device / kernel launch failed */
 
@@ -94,13 +95,16 @@ void fl_default_options(fl_options *opt, int solver);
  * workgroup), `ept` elements per thread.  Sums are taken per thread over its
  * elements, then the fixed 64-lane tree of csrc/fl_reduce.hpp (lanes l and l+32,
  * then l and l+16, then mirror steps inside a row of 16), then waves left to right -- the order
- * tests replay on the CPU to compare bit for bit.  FL_ERR_UNSUPPORTED_SIZE if n
- * is too large for the on-chip path. */
+ * tests replay on the CPU to compare bit for bit.  n <= 4096: the problem's vectors live
+ * in registers (threads <= 512, ept <= 8).  n > 4096 (SD / CG / L-BFGS): the same machine with
+ * its vectors in HBM, threads = 1024, ept = 2*ceil(ceil(n/2)/1024) (csrc/fl_big.hpp).
+ * FL_ERR_UNSUPPORTED_SIZE beyond 2^27. */
 int fl_reduction_geometry(int n, int *threads, int *ept);
 
 /* Bytes of device workspace: FL_SOLVER_LBFGS -- the (s,y) history ring,
- * [batch][2*memory][padded n] fp64; FL_SOLVER_BFGS -- the inverse Hessians [batch][n][padded n];
- * 0 for SD / CG. */
+ * [batch][2*memory][padded n] fp64 (n > 4096: plus four vector rows per problem);
+ * FL_SOLVER_BFGS -- the inverse Hessians [batch][n][padded n]; 0 for SD / CG (n > 4096: their four
+ * vector rows come from the stream-ordered allocator inside the call). */
 size_t fl_workspace_bytes(int solver, int batch, int n, int memory);
 /* the same from an option block: BFGS with exact_step > 0 needs three matrices per problem (inverse
  * Hessian, Hessian / Cholesky factor, inverse factor), FL_SOLVER_NEWTON one */
