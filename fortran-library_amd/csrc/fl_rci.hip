@@ -105,6 +105,70 @@ __global__ __launch_bounds__(1024) void rci_step_big_kernel(SolveArgs A, int fir
     if (threadIdx.x == 0) request[prob] = rq;
 }
 
+// ------------------------------------------------------------------ the line searchers on their own
+// Wolfe / StrongWolfe (+ _fdwithf) are public procedures of the reference module (NO.f90:1286, 1373, 1462, 1582):
+// one search along a given p.  Same machine (fl_linesearch.hpp), parked in HBM between evaluations; the trial
+// point x = x0 + a p and phi'(a) = g.p are formed here in the geometry fl_reduction_geometry(n) reports.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void line_search_step_kernel(int n, int nslot, int first, int strong, int fused,
+                                                                   double c1, double c2, double incr, double a0,
+                                                                   double fx0, double phid0, const double *x0,
+                                                                   const double *p, double *x, const double *g,
+                                                                   const double *f_in, double *sc, int32_t *request)
+{
+    constexpr int T = NW * 64;
+    __shared__ double slots[2 * Reducer<NW>::NVMAX * NW];
+    Reducer<NW> R{slots, 0};
+    LineSearch ls;
+    const int tid = threadIdx.x;
+    int rq;
+    double fv = 0.0, pv = 0.0;
+    if (first) {
+        rq = ls.begin(strong, fused, c1, c2, incr, a0, fx0, phid0);
+    } else {
+        const double *q = sc;
+        ls.c1 = *q++; ls.c2abs = *q++; ls.incr = *q++; ls.fx0 = *q++; ls.phid0 = *q++;
+        ls.a = *q++; ls.aold = *q++; ls.fx = *q++; ls.fold = *q++; ls.phidnew = *q++; ls.phidold = *q++;
+        ls.low = *q++; ls.up = *q++; ls.flow = *q++; ls.fup = *q++; ls.phidlow = *q++; ls.phidup = *q++;
+        ls.plma = *q++; ls.a_eval = *q++; fv = *q++; pv = *q++;
+        const int *iq = reinterpret_cast<const int *>(sc + 24);
+        ls.st = iq[0]; ls.zret = iq[1]; ls.fused = iq[2];
+        const int pending = iq[3];
+        __syncthreads(); // all waves have read the parked state before thread 0 rewrites it
+        if (pending & FL_REQ_F) fv = *f_in;
+        if (pending & FL_REQ_G) {
+            double r[1] = {0.0};
+            for (int c = 0; c < nslot; ++c) {
+                const int e = (c * T + tid) << 1;
+                const double ta = (e < n) ? g[e] * p[e] : 0.0, tb = (e + 1 < n) ? g[e + 1] * p[e + 1] : 0.0;
+                r[0] = (c == 0) ? ta : r[0] + ta;
+                r[0] = r[0] + tb;
+            }
+            R.run(r);
+            pv = r[0];
+        }
+        rq = ls.step(fv, pv);
+    }
+    if (rq != 0 && !(rq & FL_REQ_SAME)) {
+        const double at = ls.a_eval;
+        for (int c = 0; c < nslot; ++c) {
+            const int e = (c * T + tid) << 1;
+            if (e < n) x[e] = x0[e] + at * p[e];
+            if (e + 1 < n) x[e + 1] = x0[e + 1] + at * p[e + 1];
+        }
+    }
+    if (tid == 0) {
+        double *q = sc;
+        *q++ = ls.c1; *q++ = ls.c2abs; *q++ = ls.incr; *q++ = ls.fx0; *q++ = ls.phid0;
+        *q++ = ls.a; *q++ = ls.aold; *q++ = ls.fx; *q++ = ls.fold; *q++ = ls.phidnew; *q++ = ls.phidold;
+        *q++ = ls.low; *q++ = ls.up; *q++ = ls.flow; *q++ = ls.fup; *q++ = ls.phidlow; *q++ = ls.phidup;
+        *q++ = ls.plma; *q++ = ls.a_eval; *q++ = fv; *q++ = pv;
+        int *iq = reinterpret_cast<int *>(sc + 24);
+        iq[0] = ls.st; iq[1] = ls.zret; iq[2] = ls.fused; iq[3] = rq;
+        *request = rq;
+    }
+}
+
 struct Rci {
     int solver, batch, n, nw, ept, first;
     SolveArgs A;
@@ -395,6 +459,75 @@ static int legacy_solve(int solver, const char *name, const HostObjective &ob, d
     return ok ? status : FL_ERR_NO_DEVICE;
 }
 
+// One line search with host callbacks (the public Wolfe / StrongWolfe procedures).  On exit, like the reference:
+// a = the accepted step, x = x + a p, fx = f(x), fdx = f'(x).
+static void legacy_line_search(int strong, int fused, const double *c1, const double *c2, f_cb f, fd_cb fd, ffd_cb f_fd,
+                               double *x, double *a, const double *p, double *fx, const double *phid0, double *fdx,
+                               const int *dim, const double *Increment)
+{
+    const int n = *dim;
+    int threads = 0, ept = 0;
+    if (n <= 0 || fl_reduction_geometry(n, &threads, &ept) != FL_OK) {
+        std::fprintf(stderr, "FortranLibrary(MI355X) line search: unsupported dimension %d; x is unchanged\n", n);
+        return;
+    }
+    const double incr = Increment ? *Increment : 1.05; // fail-safe max(1+1d-15, Increment) inside the machine
+    double *x0d = nullptr, *pd = nullptr, *xd = nullptr, *gd = nullptr, *fd_dev = nullptr, *sc = nullptr;
+    int32_t *rqd = nullptr;
+    const size_t vb = sizeof(double) * (size_t)n;
+    bool ok = hipMalloc((void **)&x0d, vb) == hipSuccess && hipMalloc((void **)&pd, vb) == hipSuccess &&
+              hipMalloc((void **)&xd, vb) == hipSuccess && hipMalloc((void **)&gd, vb) == hipSuccess &&
+              hipMalloc((void **)&fd_dev, sizeof(double)) == hipSuccess &&
+              hipMalloc((void **)&sc, 32 * sizeof(double)) == hipSuccess &&
+              hipMalloc((void **)&rqd, sizeof(int32_t)) == hipSuccess;
+    ok = ok && hipMemcpy(x0d, x, vb, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(xd, x, vb, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(pd, p, vb, hipMemcpyHostToDevice) == hipSuccess;
+    int32_t rq = 0;
+    int first = 1;
+    double fv = *fx;
+    const int nw = threads / 64, nslot = ept / 2;
+    while (ok) {
+#define FL_LS(NW_)                                                                                                \
+    hipLaunchKernelGGL((fl::line_search_step_kernel<NW_>), dim3(1), dim3(NW_ * 64), 0, nullptr, n, nslot, first,       \
+                       strong, fused, *c1, *c2, incr, *a, *fx, *phid0, x0d, pd, xd, gd, fd_dev, sc, rqd)
+        switch (nw) {
+        case 1: FL_LS(1); break;
+        case 2: FL_LS(2); break;
+        case 4: FL_LS(4); break;
+        case 8: FL_LS(8); break;
+        default: FL_LS(16); break;
+        }
+#undef FL_LS
+        first = 0;
+        if (hipMemcpy(&rq, rqd, sizeof rq, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+        if (rq == 0) break;
+        if (!(rq & FL_REQ_SAME))
+            if (hipMemcpy(x, xd, vb, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+        const bool wf = rq & FL_REQ_F, wg = rq & FL_REQ_G;
+        if (wf && wg && f_fd) {
+            (void)f_fd(fv, fdx, x, n);
+        } else {
+            if (wf) f(fv, x, n);
+            if (wg) fd(fdx, x, n);
+        }
+        if (wf) ok = ok && hipMemcpy(fd_dev, &fv, sizeof fv, hipMemcpyHostToDevice) == hipSuccess;
+        if (wg) ok = ok && hipMemcpy(gd, fdx, vb, hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (ok) {
+        double st[8];
+        ok = hipMemcpy(st, sc, sizeof st, hipMemcpyDeviceToHost) == hipSuccess;
+        if (ok) {
+            *a = st[5];  // ls.a
+            *fx = st[7]; // ls.fx
+        }
+    }
+    if (!ok) std::fprintf(stderr, "FortranLibrary(MI355X) line search: HIP error\n");
+    void *bufs[] = {x0d, pd, xd, gd, fd_dev, sc, rqd};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+}
+
 // optional dummy arguments arrive as NULL when absent (Fortran callers); C++ always passes all
 static void legacy_options(fl_options &o, int solver, const int32_t *Strong, const int *MaxIteration,
                            const double *Precision, const double *MinStepLength, const double *WolfeConst1,
@@ -670,6 +803,60 @@ void nonlinearoptimization_mp_bfgs_(f_cb f, fd_cb fd, double *x, const int *dim,
 {
     __nonlinearoptimization_MOD_bfgs(f, fd, x, dim, fdd, ExactStep, f_fd, Strong, Warning, MaxIteration, Precision,
                                      MinStepLength, WolfeConst1, WolfeConst2, Increment);
+}
+
+// subroutine Wolfe / Wolfe_fdwithf / StrongWolfe / StrongWolfe_fdwithf (c1,c2,f,fd[,f_fd],x,a,p,fx,phid0,fdx,dim,Increment)
+// NO.f90:1286, 1373, 1462, 1582.  Wolfe_fdwithf has the body of Wolfe: it never calls f_fd.
+void __nonlinearoptimization_MOD_wolfe(const double *c1, const double *c2, f_cb f, fd_cb fd, double *x, double *a,
+                                       const double *p, double *fx, const double *phid0, double *fdx, const int *dim,
+                                       const double *Increment)
+{
+    legacy_line_search(0, 0, c1, c2, f, fd, nullptr, x, a, p, fx, phid0, fdx, dim, Increment);
+}
+void __nonlinearoptimization_MOD_wolfe_fdwithf(const double *c1, const double *c2, f_cb f, fd_cb fd, ffd_cb f_fd,
+                                               double *x, double *a, const double *p, double *fx, const double *phid0,
+                                               double *fdx, const int *dim, const double *Increment)
+{
+    (void)f_fd;
+    legacy_line_search(0, 0, c1, c2, f, fd, nullptr, x, a, p, fx, phid0, fdx, dim, Increment);
+}
+void __nonlinearoptimization_MOD_strongwolfe(const double *c1, const double *c2, f_cb f, fd_cb fd, double *x, double *a,
+                                             const double *p, double *fx, const double *phid0, double *fdx,
+                                             const int *dim, const double *Increment)
+{
+    legacy_line_search(1, 0, c1, c2, f, fd, nullptr, x, a, p, fx, phid0, fdx, dim, Increment);
+}
+void __nonlinearoptimization_MOD_strongwolfe_fdwithf(const double *c1, const double *c2, f_cb f, fd_cb fd, ffd_cb f_fd,
+                                                     double *x, double *a, const double *p, double *fx,
+                                                     const double *phid0, double *fdx, const int *dim,
+                                                     const double *Increment)
+{
+    legacy_line_search(1, f_fd != nullptr, c1, c2, f, fd, f_fd, x, a, p, fx, phid0, fdx, dim, Increment);
+}
+void nonlinearoptimization_mp_wolfe_(const double *c1, const double *c2, f_cb f, fd_cb fd, double *x, double *a,
+                                     const double *p, double *fx, const double *phid0, double *fdx, const int *dim,
+                                     const double *Increment)
+{
+    __nonlinearoptimization_MOD_wolfe(c1, c2, f, fd, x, a, p, fx, phid0, fdx, dim, Increment);
+}
+void nonlinearoptimization_mp_wolfe_fdwithf_(const double *c1, const double *c2, f_cb f, fd_cb fd, ffd_cb f_fd, double *x,
+                                             double *a, const double *p, double *fx, const double *phid0, double *fdx,
+                                             const int *dim, const double *Increment)
+{
+    __nonlinearoptimization_MOD_wolfe_fdwithf(c1, c2, f, fd, f_fd, x, a, p, fx, phid0, fdx, dim, Increment);
+}
+void nonlinearoptimization_mp_strongwolfe_(const double *c1, const double *c2, f_cb f, fd_cb fd, double *x, double *a,
+                                           const double *p, double *fx, const double *phid0, double *fdx,
+                                           const int *dim, const double *Increment)
+{
+    __nonlinearoptimization_MOD_strongwolfe(c1, c2, f, fd, x, a, p, fx, phid0, fdx, dim, Increment);
+}
+void nonlinearoptimization_mp_strongwolfe_fdwithf_(const double *c1, const double *c2, f_cb f, fd_cb fd, ffd_cb f_fd,
+                                                   double *x, double *a, const double *p, double *fx,
+                                                   const double *phid0, double *fdx, const int *dim,
+                                                   const double *Increment)
+{
+    __nonlinearoptimization_MOD_strongwolfe_fdwithf(c1, c2, f, fd, f_fd, x, a, p, fx, phid0, fdx, dim, Increment);
 }
 
 } // extern "C"

@@ -18,6 +18,7 @@
 !device-resident data and built-in objectives (include/fl_nlopt.h).
 !  NewtonRaphson     <- reference NonlinearOptimization.f90:1026 (without fdd: central differences of fd)
 !  AugmentedLagrangian <- reference NonlinearOptimization.f90:2005 (inner solvers LBFGS / ConjugateGradient / BFGS)
+!  Wolfe, Wolfe_fdwithf, StrongWolfe, StrongWolfe_fdwithf <- reference NonlinearOptimization.f90:1286, 1373, 1462, 1582
 !Not provided (SURVEY.md sections 2, 8f): TrustRegion (MKL RCI), LagrangianMultiplier.
 module NonlinearOptimization
     use iso_c_binding
@@ -87,6 +88,27 @@ module NonlinearOptimization
             type(c_ptr),value::Strong,Warning,MaxIteration,Precision,MinStepLength,WolfeConst1,WolfeConst2,Increment
             integer(c_int),value::len_UnconstrainedSolver,len_Method
         end subroutine flc_augmentedlagrangian
+        subroutine flc_linesearch(c1,c2,f,fd,x,a,p,fx,phid0,fdx,dim,Increment) bind(C,name='__nonlinearoptimization_MOD_wolfe')
+            import
+            real(c_double),intent(in)::c1,c2,phid0
+            type(c_funptr),value::f,fd
+            real(c_double)::x(*),fdx(*)
+            real(c_double),intent(in)::p(*)
+            real(c_double),intent(inout)::a,fx
+            integer(c_int),intent(in)::dim
+            type(c_ptr),value::Increment
+        end subroutine flc_linesearch
+        subroutine flc_stronglinesearch(c1,c2,f,fd,f_fd,x,a,p,fx,phid0,fdx,dim,Increment)&
+        bind(C,name='__nonlinearoptimization_MOD_strongwolfe_fdwithf')
+            import
+            real(c_double),intent(in)::c1,c2,phid0
+            type(c_funptr),value::f,fd,f_fd
+            real(c_double)::x(*),fdx(*)
+            real(c_double),intent(in)::p(*)
+            real(c_double),intent(inout)::a,fx
+            integer(c_int),intent(in)::dim
+            type(c_ptr),value::Increment
+        end subroutine flc_stronglinesearch
         subroutine fl_default_options(opt,solver) bind(C,name='fl_default_options')
             import
             type(fl_options),intent(out)::opt
@@ -117,6 +139,73 @@ contains
 !-------------- Line search --------------
     !Optional arguments travel as C pointers: the address of a local copy when present, NULL when absent
     !(the convention of the reference's C++ header, cpp/README.md:11-18); logical -> 4-byte integer
+
+    !Line searchers (reference NonlinearOptimization.f90:1286, 1373, 1462, 1582): public in the reference module.
+    !Input:  Wolfe constants c1 & c2, x, initial guess a, direction p, fx = f(x), phid0 = phi'(0)
+    !Output: a = accepted step, x = x + a * p, fx = f(x), fdx = f'(x)
+    subroutine Wolfe(c1, c2, f, fd, x, a, p, fx, phid0, fdx, dim, Increment)
+        real*8,intent(in)::c1,c2
+        external::f,fd
+        integer,intent(in)::dim
+        real*8,dimension(dim),intent(inout)::x
+        real*8,intent(inout)::a
+        real*8,dimension(dim),intent(in)::p
+        real*8,intent(inout)::fx
+        real*8,intent(in)::phid0
+        real*8,dimension(dim),intent(out)::fdx
+        real*8,intent(in),optional::Increment
+        real(c_double),target::li
+        type(c_ptr)::pinc
+        pinc=c_null_ptr; if(present(Increment)) then; li=Increment; pinc=c_loc(li); end if
+        call flc_linesearch(c1,c2,c_funloc(f),c_funloc(fd),x,a,p,fx,phid0,fdx,dim,pinc)
+    end subroutine Wolfe
+    subroutine Wolfe_fdwithf(c1, c2, f, fd, f_fd, x, a, p, fx, phid0, fdx, dim, Increment)!never calls f_fd (reference 1373)
+        real*8,intent(in)::c1,c2
+        external::f,fd
+        integer,external::f_fd
+        integer,intent(in)::dim
+        real*8,dimension(dim),intent(inout)::x
+        real*8,intent(inout)::a
+        real*8,dimension(dim),intent(in)::p
+        real*8,intent(inout)::fx
+        real*8,intent(in)::phid0
+        real*8,dimension(dim),intent(out)::fdx
+        real*8,intent(in),optional::Increment
+        call Wolfe(c1,c2,f,fd,x,a,p,fx,phid0,fdx,dim,Increment)
+    end subroutine Wolfe_fdwithf
+    subroutine StrongWolfe(c1, c2, f, fd, x, a, p, fx, phid0, fdx, dim, Increment)
+        real*8,intent(in)::c1,c2
+        external::f,fd
+        integer,intent(in)::dim
+        real*8,dimension(dim),intent(inout)::x
+        real*8,intent(inout)::a
+        real*8,dimension(dim),intent(in)::p
+        real*8,intent(inout)::fx
+        real*8,intent(in)::phid0
+        real*8,dimension(dim),intent(out)::fdx
+        real*8,intent(in),optional::Increment
+        real(c_double),target::li
+        type(c_ptr)::pinc
+        pinc=c_null_ptr; if(present(Increment)) then; li=Increment; pinc=c_loc(li); end if
+        call flc_stronglinesearch(c1,c2,c_funloc(f),c_funloc(fd),c_null_funptr,x,a,p,fx,phid0,fdx,dim,pinc)
+    end subroutine StrongWolfe
+    subroutine StrongWolfe_fdwithf(c1, c2, f, fd, f_fd, x, a, p, fx, phid0, fdx, dim, Increment)
+        real*8,intent(in)::c1,c2
+        external::f,fd
+        integer,external::f_fd
+        integer,intent(in)::dim
+        real*8,dimension(dim),intent(inout)::x
+        real*8,intent(inout)::a
+        real*8,dimension(dim),intent(in)::p
+        real*8,intent(inout)::fx
+        real*8,intent(in)::phid0
+        real*8,dimension(dim),intent(out)::fdx
+        real*8,intent(in),optional::Increment
+        real(c_double),target::li
+        type(c_ptr)::pinc
+        pinc=c_null_ptr; if(present(Increment)) then; li=Increment; pinc=c_loc(li); end if
+        call flc_stronglinesearch(c1,c2,c_funloc(f),c_funloc(fd),c_funloc(f_fd),x,a,p,fx,phid0,fdx,dim,pinc)
+    end subroutine StrongWolfe_fdwithf
 
     subroutine SteepestDescent(f, fd, x, dim, &
     f_fd, Strong, Warning, MaxIteration, Precision, MinStepLength, WolfeConst1, WolfeConst2, Increment)

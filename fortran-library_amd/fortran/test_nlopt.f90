@@ -68,7 +68,8 @@ program main
     implicit none
     integer,parameter::dim=10
     integer::i
-    real*8,dimension(dim)::x
+    real*8,dimension(dim)::x,g,pdir
+    real*8::fx0,fx1,a
     write(*,*)'Steepest descent'
     call start(); call SteepestDescent(f,fd,x,dim,Warning=.false.,MaxIteration=300); write(*,'(A,ES24.16)')' SD ',norm2(x)
     write(*,*)'Conjugate gradient'
@@ -95,6 +96,12 @@ program main
         MaxIteration=100,Precision=1d-10); write(*,'(A,ES24.16)')' AugLag-LBFGS ',abs(norm2(x)-1d0)
     call start(); call AugmentedLagrangian(f,fd,c,cd,x,dim,1,UnconstrainedSolver='ConjugateGradient',Method='PR',f_fd=f_fd,&
         Warning=.false.,MaxIteration=100,Precision=1d-10); write(*,'(A,ES24.16)')' AugLag-CG-PR ',abs(norm2(x)-1d0)
+    write(*,*)'Line searchers along -f''(x): f must decrease'
+    call start(); call f(fx0,x,dim); call fd(g,x,dim); pdir=-g; fx1=fx0; a=1d0
+    call StrongWolfe(1d-4,0.9d0,f,fd,x,a,pdir,fx1,-dot_product(g,g),g,dim); write(*,'(A,ES24.16)')' StrongWolfe-f/f0 ',fx1/fx0
+    call start(); call fd(g,x,dim); pdir=-g; fx1=fx0; a=1d0
+    call Wolfe_fdwithf(1d-4,0.9d0,f,fd,f_fd,x,a,pdir,fx1,-dot_product(g,g),g,dim,Increment=1.5d0)
+    write(*,'(A,ES24.16)')' Wolfe-f/f0 ',fx1/fx0
     write(*,*)'Mission complete'
 contains
     subroutine start()

@@ -87,6 +87,37 @@ void nonlinearoptimization_mp_lbfgs_(fl_f_cb f, fl_fd_cb fd, double *x, const in
 void nonlinearoptimization_mp_bfgs_(fl_f_cb f, fl_fd_cb fd, double *x, const int *dim, fl_fdd_cb fdd,
                                     const int *ExactStep, fl_f_fd_cb f_fd, FL_LEGACY_COMMON_ARGS);
 
+/* The line searchers are public procedures of the reference module too (NO.f90:1286, 1373, 1462, 1582):
+ * subroutine StrongWolfe(c1,c2,f,fd,x,a,p,fx,phid0,fdx,dim,Increment) etc.  In: x, trial step a, direction p,
+ * fx = f(x), phid0 = f'(x).p; out: a, x = x + a p, fx = f(x), fdx = f'(x).  Increment may be NULL (1.05). */
+void __nonlinearoptimization_MOD_wolfe(const double *c1, const double *c2, fl_f_cb f, fl_fd_cb fd, double *x, double *a,
+                                       const double *p, double *fx, const double *phid0, double *fdx, const int *dim,
+                                       const double *Increment);
+void __nonlinearoptimization_MOD_wolfe_fdwithf(const double *c1, const double *c2, fl_f_cb f, fl_fd_cb fd,
+                                               fl_f_fd_cb f_fd, double *x, double *a, const double *p, double *fx,
+                                               const double *phid0, double *fdx, const int *dim,
+                                               const double *Increment);
+void __nonlinearoptimization_MOD_strongwolfe(const double *c1, const double *c2, fl_f_cb f, fl_fd_cb fd, double *x,
+                                             double *a, const double *p, double *fx, const double *phid0, double *fdx,
+                                             const int *dim, const double *Increment);
+void __nonlinearoptimization_MOD_strongwolfe_fdwithf(const double *c1, const double *c2, fl_f_cb f, fl_fd_cb fd,
+                                                     fl_f_fd_cb f_fd, double *x, double *a, const double *p,
+                                                     double *fx, const double *phid0, double *fdx, const int *dim,
+                                                     const double *Increment);
+void nonlinearoptimization_mp_wolfe_(const double *c1, const double *c2, fl_f_cb f, fl_fd_cb fd, double *x, double *a,
+                                     const double *p, double *fx, const double *phid0, double *fdx, const int *dim,
+                                     const double *Increment);
+void nonlinearoptimization_mp_wolfe_fdwithf_(const double *c1, const double *c2, fl_f_cb f, fl_fd_cb fd, fl_f_fd_cb f_fd,
+                                             double *x, double *a, const double *p, double *fx, const double *phid0,
+                                             double *fdx, const int *dim, const double *Increment);
+void nonlinearoptimization_mp_strongwolfe_(const double *c1, const double *c2, fl_f_cb f, fl_fd_cb fd, double *x,
+                                           double *a, const double *p, double *fx, const double *phid0, double *fdx,
+                                           const int *dim, const double *Increment);
+void nonlinearoptimization_mp_strongwolfe_fdwithf_(const double *c1, const double *c2, fl_f_cb f, fl_fd_cb fd,
+                                                   fl_f_fd_cb f_fd, double *x, double *a, const double *p, double *fx,
+                                                   const double *phid0, double *fdx, const int *dim,
+                                                   const double *Increment);
+
 /* Import-time symbols of the reference's Python package (FortranLibrary/General.py:4-16 probes
  * general_mp_showtime_ / __general_MOD_showtime when the package is imported, so `CDLL('libFL.so')` users keep
  * importing it against this library).  Host utilities, restated from source/General.f90:29-55:
