@@ -5,7 +5,7 @@ Not the driver's bench (that is bench.py = the north-star headline); this record
 for the remaining rows of SURVEY.md section 8.  Same method: inputs generated on the device, one launch of the
 fused kernel per solve, HIP events on the launch stream, algorithmic bytes per SURVEY.md 8(d), CPU oracle
 (reference summation order, OpenMP one problem per thread on the cgroup's cores) on a bounded sample.
-usage: python tools/bench_configs.py [c2 c3 c4 c5] [--cpu-seconds 10]
+usage: python tools/bench_configs.py [c1 c2 c3 c4 c4gemm c5 newton dense] [--cpu-seconds 10]
 """
 import argparse
 import json
@@ -171,6 +171,91 @@ def main():
                           "ms": ms, "TFLOPs": flop / ms / 1e9, "peak_TFLOPs_datasheet": PEAK, "frac": flop / ms / 1e9 / PEAK,
                           "ms_per_problem_update": ms / B,
                           "rank2_form_ms_per_problem_update_at_5.6TBps": 24.0 * n * n * 8 / 5.6e12 * 1e3 / 8}))
+
+    if "c1" in args.configs:  # BASELINE config 1: one Rosenbrock n=10 problem, BFGS, standard start -- plumbing, not throughput
+        n = 10
+        x0 = torch.full((1, n), -1.2, dtype=torch.float64, device=dev)
+        x0[:, 1::2] = 1.0
+        for es, label in ((0, "ExactStep=0"), (20, "ExactStep=20 (analytic Hessian refresh)")):
+            for B in (1, 65536):
+                xb = x0.expand(B, n).contiguous()
+                x = torch.empty_like(xb)
+                ws = NLO.bfgs_workspace(B, n, dev, NLO.default_options(NLO.BFGS_, ExactStep=es))
+
+                def run():
+                    x.copy_(xb)
+                    return NLO.BFGS(NLO.ROSENBROCK, x, workspace_=ws, ExactStep=es)
+                out, ms = timed(run, 3)
+                ref = O.solve_batch(O.BFGS, O.ROSENBROCK, x0.cpu().numpy(), opts=O.defaults(exact_step=es), bfgs_form=1)
+                t = time.perf_counter()
+                for _ in range(20):
+                    O.solve_batch(O.BFGS, O.ROSENBROCK, x0.cpu().numpy(), opts=O.defaults(exact_step=es), bfgs_form=1)
+                cpu_ms = (time.perf_counter() - t) / 20 * 1e3
+                print(json.dumps({"config": f"C1 BFGS {label}, Rosenbrock n=10 standard start, batch {B} (replicas)", "ms": ms,
+                                  "iterations": int(out["iters"][0]), "nf": int(out["nf"][0]), "ng": int(out["ng"][0]),
+                                  "f": float(out["f"][0]), "max_abs_x_minus_1": float((x - 1).abs().max()),
+                                  "problems_per_s": B / ms * 1e3, "cpu_ms_one_problem_one_core": cpu_ms,
+                                  "cpu_iterations": int(ref["iters"][0]), "cpu_f": float(ref["f"][0])}))
+
+    if "newton" in args.configs:  # NewtonRaphson with the analytic Hessian, dense Cholesky per iteration
+        for B, n in ((4096, 256), (256, 1024)):
+            x0 = torch.empty(B, n, dtype=torch.float64, device=dev)
+            NLO.synth_uniform(SEED, x0, 0.9, 1.1)
+            x = torch.empty_like(x0)
+            ws = NLO.bfgs_workspace(B, n, dev, NLO.default_options(NLO.NEWTON_), NLO.NEWTON_)
+
+            def run():
+                x.copy_(x0)
+                return NLO.NewtonRaphson(NLO.ROSENBROCK, x, workspace_=ws, Precision=1e-10, MaxIteration=100)
+            out, ms = timed(run, 2)
+            it = out["iters"].to(torch.int64)
+            flop = float(it.sum()) * (n ** 3 / 3.0 + 2.0 * n * n)  # Cholesky + two triangular solves per iteration
+            byts = float(it.sum()) * (n * n * 8 * 2.0)              # Hessian written once, factor read back once (lower bound)
+            Bc = min(B, 2 * cores)
+            t = time.perf_counter()
+            ref = O.solve_batch(4, O.ROSENBROCK, x0[:Bc].cpu().numpy(), opts=O.defaults(precision=1e-10, maxit=100), nthreads=cores)
+            dt = time.perf_counter() - t
+            print(json.dumps({"config": f"NewtonRaphson (analytic Hessian, Cholesky solve), Rosenbrock n={n}, batch {B}", "ms": ms,
+                              "iterations": int(it.sum()), "iterations_per_s": float(it.sum()) / ms * 1e3,
+                              "converged_fraction": float((out["status"] == 0).double().mean()),
+                              "GFLOPs_cholesky_model": flop / ms / 1e6, "GBps_lower_bound": byts / ms / 1e6,
+                              "max_abs_x_minus_1": float((x - 1).abs().max()),
+                              "cpu_iterations_per_s": float(ref["iters"].sum()) / dt, "cpu": host, "cpu_sample": Bc}))
+
+    if "dense" in args.configs:  # My_dposv / My_dpotri for batches (LA.f90:719-730, 798-812)
+        for B, n in ((4096, 256), (256, 1024), (16, 4096)):
+            T, E = NLO.reduction_geometry(n)
+            ld = T * E
+            g = torch.randn(B, n, n, dtype=torch.float64, device=dev)
+            spd = g @ g.transpose(1, 2) / n + torch.eye(n, dtype=torch.float64, device=dev)
+            A0 = torch.zeros(B, n, ld, dtype=torch.float64, device=dev)
+            A0[:, :, :n] = spd  # symmetric: row / column major agree
+            rhs0 = torch.randn(B, n, dtype=torch.float64, device=dev)
+            A, rhs = torch.empty_like(A0), torch.empty_like(rhs0)
+
+            def run_sv():
+                A.copy_(A0)
+                rhs.copy_(rhs0)
+                return NLO.dposv(A, rhs)
+
+            def run_copy():
+                A.copy_(A0)
+                rhs.copy_(rhs0)
+                return None
+            _, ms_copy = timed(run_copy, 3)
+            info, ms = timed(run_sv, 3)
+            res = float(((spd @ rhs.unsqueeze(2)).squeeze(2) - rhs0).abs().max())
+
+            def run_tri():
+                A.copy_(A0)
+                return NLO.dpotri(A)
+            info2, ms2 = timed(run_tri, 3)
+            err = float((A[:, :, :n] @ spd - torch.eye(n, dtype=torch.float64, device=dev)).abs().max())
+            print(json.dumps({"config": f"dense SPD kernels n={n}, batch {B}", "dposv_ms": ms - ms_copy,
+                              "dposv_GFLOPs": B * (n ** 3 / 3.0 + 2.0 * n * n) / (ms - ms_copy) / 1e6,
+                              "dposv_max_residual": res, "dpotri_ms": ms2 - ms_copy,
+                              "dpotri_GFLOPs": B * (n ** 3) / (ms2 - ms_copy) / 1e6, "dpotri_max_abs_AinvA_minus_I": err,
+                              "all_info_zero": bool((info == 0).all() and (info2 == 0).all())}))
 
     if "c5" in args.configs:  # aug-Lagrangian wrapping L-BFGS, batch 8192 n=512, 8 equality constraints
         B, n, M, m = 8192, 512, 8, 10
