@@ -316,7 +316,16 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
     static constexpr int LDS_PAIRS = LDS_PAIRS_WANT < LDS_PAIRS_FIT ? LDS_PAIRS_WANT : LDS_PAIRS_FIT;
     static constexpr int L_BF = L_G0 + ((NEEDS_G0 && METHOD != FL_SOLVER_BFGS) ? (LDS_PAIRS > 0 ? 2 * LDS_PAIRS * NPAD : NPAD) : 0);
     // Newton: one row buffer for the Cholesky kernels (BFGS reuses its broadcast arrays)
-    static constexpr int LDS_TOTAL = L_BF + (METHOD == FL_SOLVER_BFGS ? 3 * NPAD : (METHOD == FL_SOLVER_NEWTON ? NPAD : 0));
+    static constexpr int L_DEF = L_BF + (METHOD == FL_SOLVER_BFGS ? 3 * NPAD : (METHOD == FL_SOLVER_NEWTON ? NPAD : 0));
+    // BFGS for n > 1024, fused kernels: the rank-2 updates are DEFERRED -- H is left alone for BF_DEFER iterations
+    // (one read pass per iteration instead of a read pass and a read+write pass), then the pending updates are folded
+    // in together (direction_bfgs_deferred).  L_DEF: rho_l, cs_l of the pending updates.
+#ifndef FL_BFGS_DEFER
+#define FL_BFGS_DEFER 8
+#endif
+    static constexpr int BF_DEFER = (METHOD == FL_SOLVER_BFGS && OBJ != FL_OBJ_EXTERNAL && NPAD >= 2048) ? FL_BFGS_DEFER : 0;
+    static constexpr int BF_FOLD_COLS = 128; // columns whose s_l[j], q_l[j] are staged in LDS at a time while folding
+    static constexpr int LDS_TOTAL = L_DEF + 2 * BF_DEFER;
     using DN = Dense<NW, EPT>;
 
     const SolveArgs &A;
@@ -331,6 +340,8 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
     int recent, cnt;    // L-BFGS ring
     int lrec;           // slot of the newest pair in the LDS ring (LDS_PAIRS > 0)
     int main_it, h_valid; // BFGS / Newton: main-loop iteration counter (iIteration), inverse Hessian initialised
+    int ndef, h_ident;    // deferred BFGS: pending updates; H is still the implicit a_id * I of the first step
+    double a_id;
     int hess_stage;       // reverse communication: where to resume once the caller has supplied the Hessian
     static constexpr bool HESS_RCI = (OBJ == FL_OBJ_EXTERNAL);
     double yy_recent, rho_recent;
@@ -351,10 +362,15 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
     {
         if constexpr (METHOD == FL_SOLVER_LBFGS) return A.hist + (size_t)prob * (size_t)(2 * A.mem) * NPAD;
         // BFGS: H [n][NPAD]; with ExactStep > 0 also U (exact Hessian / its Cholesky factor) and W (inverse factor)
+        // (fused kernels, n > 1024: plus 2*BF_DEFER rows for the pending updates' s_l, q_l)
         if constexpr (METHOD == FL_SOLVER_BFGS)
-            return A.hist + (size_t)prob * (size_t)(A.exact_step > 0 ? 3 : 1) * (size_t)n * NPAD;
+            return A.hist + (size_t)prob * ((size_t)(A.exact_step > 0 ? 3 : 1) * (size_t)n + 2 * BF_DEFER) * NPAD;
         if constexpr (METHOD == FL_SOLVER_NEWTON) return A.hist + (size_t)prob * (size_t)n * NPAD;
         return nullptr;
+    }
+    __device__ __forceinline__ double *deferred_rows() const // [2*BF_DEFER][NPAD]: s_0, q_0, s_1, q_1, ...
+    {
+        return hist_base() + (size_t)(A.exact_step > 0 ? 3 : 1) * (size_t)n * NPAD;
     }
     // LDS rows of the slot-th pair of the LDS ring (s row, then y row)
     __device__ __forceinline__ double *lds_pair(int slot) const { return lds + L_G0 + (size_t)(2 * slot) * NPAD; }
@@ -383,6 +399,9 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
         cnt = 0;
         main_it = 0;
         h_valid = 0;
+        ndef = 0;
+        h_ident = 0;
+        a_id = 0.0;
         hess_stage = 0;
         yy_recent = rho_recent = 0.0;
         fnew = gg = pp = phid = phidold = a = 0.0;
@@ -679,6 +698,8 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
         if (DN::cholesky(U, n, lds + L_BF, lds + L_CX) != 0) return false;
         DN::inverse_factor(U, W, n, lds + L_BF);
         DN::wtw(W, Hm, n, lds + L_BF);
+        ndef = 0; // pending updates belonged to the matrix that has just been replaced
+        h_ident = 0;
         neg_matvec(Hm, lds + L_BF + 2 * NPAD);
         direction_scalars();
         return true;
@@ -732,7 +753,10 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
             // NO.f90:949-956); otherwise, or if it is not positive definite, the rank-2 update (957-963)
             bool refreshed = false;
             if (A.exact_step > 0 && h_valid && main_it % A.exact_step == 0) refreshed = bfgs_exact_refresh();
-            if (!refreshed) direction_bfgs(g0);
+            if (!refreshed) {
+                if constexpr (BF_DEFER > 0) direction_bfgs_deferred(g0);
+                else direction_bfgs(g0);
+            }
             h_valid = 1;
         }
         phid = uni(phid);
@@ -1021,6 +1045,154 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
         phid = r3[0];
         pp = r3[1];
         a = 1.0;
+    }
+
+    // The same update DEFERRED (BF_DEFER > 0; oracle update_form 100 + BF_DEFER): with the pending updates
+    //   H_{l+1} = H_l - rho_l q_l s_l^T - rho_l s_l q_l^T + cs_l s_l s_l^T,  q_l = H_l y_l,   l = 0 .. ndef-1
+    // kept as vectors, H_cur y and H_cur g are H y and H g -- ONE read pass with two accumulators per row -- plus
+    // 4 dot products and two axpy-like corrections per pending update; the new update joins the list, p = -H_new g
+    // follows algebraically, and every BF_DEFER-th iteration the list is folded into H element by element in the
+    // order the updates occurred.  HBM bytes per iteration: 8 n^2 + 16 n^2 / BF_DEFER instead of 24 n^2.
+    __device__ __forceinline__ void direction_bfgs_deferred(const double (&g0)[EPT])
+    {
+        double *H = hist_base(), *D = deferred_rows();
+        double *by = lds + L_BF, *bg = by + NPAD;
+        double *drho = lds + L_DEF, *dcs = drho + (BF_DEFER > 0 ? BF_DEFER : 1);
+        double sv[EPT], yv[EPT], q[EPT], w[EPT];
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            sv[k] = x[k] - x0[k];
+            yv[k] = g[k] - g0[k];
+        }
+        double r1[1] = {dot_part<EPT>(yv, sv)};
+        R.run(r1);
+        const double rho = uni(1.0 / r1[0]);
+        if (!h_valid) { // first quasi-Newton matrix from H = a I (NO.f90:711-715): the identity stays implicit
+            ndef = 0;
+            h_ident = 1;
+            a_id = a;
+        }
+        if (h_ident) {
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+                q[k] = a_id * yv[k];
+                w[k] = a_id * g[k];
+            }
+        } else {
+            __syncthreads();
+            store_pad<NW, EPT>(by, yv);
+            store_pad<NW, EPT>(bg, g);
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) q[k] = w[k] = 0.0;
+            for (int j = 0; j < n; j += BF_UNROLL) {
+                double h[BF_UNROLL][EPT];
+#pragma unroll
+                for (int u = 0; u < BF_UNROLL; ++u)
+                    if (j + u < n) load_pad<NW, EPT>(H + (size_t)(j + u) * NPAD, h[u]);
+#pragma unroll
+                for (int u = 0; u < BF_UNROLL; ++u) {
+                    if (j + u < n) {
+                        const double yj = by[j + u], gj = bg[j + u];
+#pragma unroll
+                        for (int k = 0; k < EPT; ++k) {
+                            q[k] = q[k] + h[u][k] * yj;
+                            w[k] = w[k] + h[u][k] * gj;
+                        }
+                    }
+                }
+            }
+        }
+        for (int l = 0; l < ndef; ++l) { // corrections of the pending updates, oldest first
+            double S[EPT], Q[EPT];
+            load_pad<NW, EPT>(D + (size_t)(2 * l) * NPAD, S);
+            load_pad<NW, EPT>(D + (size_t)(2 * l + 1) * NPAD, Q);
+            double r[4] = {dot_part<EPT>(S, yv), dot_part<EPT>(Q, yv), dot_part<EPT>(S, g), dot_part<EPT>(Q, g)};
+            R.run(r);
+            const double rl = drho[l], cl = dcs[l];
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+                const double rq = rl * Q[k], rs = rl * S[k], cc_ = cl * S[k];
+                q[k] = q[k] - rq * r[0] - rs * r[1] + cc_ * r[0];
+                w[k] = w[k] - rq * r[2] - rs * r[3] + cc_ * r[2];
+            }
+        }
+        double r3[3] = {dot_part<EPT>(yv, q), dot_part<EPT>(sv, g), dot_part<EPT>(q, g)};
+        R.run(r3);
+        const double cs = uni(rho * rho * r3[0] + rho);
+#pragma unroll
+        for (int k = 0; k < EPT; ++k)
+            p[k] = -(w[k] - (rho * q[k]) * r3[1] - (rho * sv[k]) * r3[2] + (cs * sv[k]) * r3[1]); // p=-matmul(H,fdnew)
+        store_pad<NW, EPT>(D + (size_t)(2 * ndef) * NPAD, sv);
+        store_pad<NW, EPT>(D + (size_t)(2 * ndef + 1) * NPAD, q);
+        if (threadIdx.x == 0) {
+            drho[ndef] = rho;
+            dcs[ndef] = cs;
+        }
+        ++ndef;
+        __syncthreads(); // rho_l, cs_l and the rows of this update are visible to the workgroup
+        if (ndef == BF_DEFER) bfgs_fold();
+        double r4[2] = {dot_part<EPT>(g, p), dot_part<EPT>(p, p)};
+        R.run(r4);
+        phid = r4[0];
+        pp = r4[1];
+        a = 1.0;
+    }
+    // H <- H with the pending updates applied in order.  Each thread sweeps the columns once per 16-byte chunk of
+    // its rows (the row factors of all pending updates for EPT rows at once would not fit the registers); the
+    // s_l[j], q_l[j] of BF_FOLD_COLS columns at a time are staged in LDS.
+    __device__ __forceinline__ void bfgs_fold()
+    {
+        constexpr int J = BF_DEFER > 0 ? BF_DEFER : 1, CB = BF_FOLD_COLS;
+        double *H = hist_base(), *D = deferred_rows();
+        double *stage = lds + L_BF; // [2*J][CB]
+        const double *drho = lds + L_DEF, *dcs = drho + J;
+        static_assert(BF_DEFER == 0 || 2 * J * CB <= 3 * NPAD, "staging area");
+        for (int c = 0; c < G::NCH; ++c) {
+            const int e = G::e0(c);
+            double rq[J][2], rs[J][2], cf[J][2];
+#pragma unroll
+            for (int l = 0; l < J; ++l) {
+                const double2 S = *reinterpret_cast<const double2 *>(D + (size_t)(2 * l) * NPAD + e);
+                const double2 Q = *reinterpret_cast<const double2 *>(D + (size_t)(2 * l + 1) * NPAD + e);
+                const double rl = drho[l], cl = dcs[l];
+                rq[l][0] = rl * Q.x; rq[l][1] = rl * Q.y;
+                rs[l][0] = rl * S.x; rs[l][1] = rl * S.y;
+                cf[l][0] = cl * S.x; cf[l][1] = cl * S.y;
+            }
+            for (int jb = 0; jb < n; jb += CB) {
+                __syncthreads(); // the previous block's readers are done
+                for (int i = threadIdx.x; i < 2 * J * CB; i += G::T) {
+                    const int row = i / CB, col = i - row * CB;
+                    stage[i] = (jb + col < n) ? D[(size_t)row * NPAD + jb + col] : 0.0;
+                }
+                __syncthreads();
+                const int jend = (n - jb < CB) ? n - jb : CB;
+                for (int jj = 0; jj < jend; ++jj) {
+                    const int j = jb + jj;
+                    double2 *hp = reinterpret_cast<double2 *>(H + (size_t)j * NPAD + e);
+                    double ha, hb;
+                    if (h_ident) {
+                        ha = (e == j) ? a_id : 0.0;
+                        hb = (e + 1 == j) ? a_id : 0.0;
+                    } else {
+                        const double2 t = *hp;
+                        ha = t.x;
+                        hb = t.y;
+                    }
+#pragma unroll
+                    for (int l = 0; l < J; ++l) {
+                        const double sj = stage[(2 * l) * CB + jj], qj = stage[(2 * l + 1) * CB + jj];
+                        ha = ha - rq[l][0] * sj - rs[l][0] * qj + cf[l][0] * sj;
+                        hb = hb - rq[l][1] * sj - rs[l][1] * qj + cf[l][1] * sj;
+                    }
+                    *hp = make_double2(ha, hb);
+                }
+            }
+        }
+        __syncthreads();
+        h_ident = 0;
+        ndef = 0;
     }
 
     // ---------------------------------------------------------------- reverse communication

@@ -287,8 +287,15 @@ void fl_default_options(fl_options *o, int solver)
 size_t fl_workspace_bytes_for(int solver, int batch, int n, const fl_options *opt)
 {
     if (!opt) return 0;
-    if (solver == FL_SOLVER_BFGS) return fl_workspace_bytes(solver, batch, n, 0) * (opt->exact_step > 0 ? 3 : 1);
-    if (solver == FL_SOLVER_NEWTON) return fl_workspace_bytes(FL_SOLVER_BFGS, batch, n, 0);
+    if (solver == FL_SOLVER_BFGS || solver == FL_SOLVER_NEWTON) {
+        fl::GeoSel g;
+        if (batch <= 0 || !fl::select_geometry(n, g)) return 0;
+        const size_t npad = (size_t)(g.nw * 64 * g.ept);
+        if (solver == FL_SOLVER_NEWTON) return (size_t)batch * (size_t)n * npad * sizeof(double);
+        // H (+ Hessian / factor and inverse factor with ExactStep > 0) + the rows of the deferred updates (n > 1024)
+        const size_t defer = npad >= 2048 ? 2 * FL_BFGS_DEFER : 0;
+        return (size_t)batch * ((size_t)(opt->exact_step > 0 ? 3 : 1) * (size_t)n + defer) * npad * sizeof(double);
+    }
     return fl_workspace_bytes(solver, batch, n, opt->memory);
 }
 
@@ -324,7 +331,8 @@ size_t fl_workspace_bytes(int solver, int batch, int n, int memory)
         const size_t mem = memory > 1 ? (size_t)memory : 1;
         return (size_t)batch * 2 * mem * npad * sizeof(double);
     }
-    if (solver == FL_SOLVER_BFGS) return (size_t)batch * (size_t)n * npad * sizeof(double);
+    if (solver == FL_SOLVER_BFGS) // ExactStep <= 0; see fl_workspace_bytes_for
+        return (size_t)batch * ((size_t)n + (npad >= 2048 ? 2 * FL_BFGS_DEFER : 0)) * npad * sizeof(double);
     return 0;
 }
 

@@ -814,6 +814,81 @@ static void bfgs_update(int n, double *H, double *U, const double *s, const doub
     }
 }
 
+/* form 100+J: the rank-2 update DEFERRED (what the HIP kernels do for n > 1024, csrc/fl_device.hpp
+ * direction_bfgs_deferred): H stays as it is for J iterations, the J updates
+ *   H_{l+1} = H_l - rho_l q_l s_l^T - rho_l s_l q_l^T + cs_l s_l s_l^T,  q_l = H_l y_l
+ * are kept as (s_l, q_l, rho_l, cs_l); H_l y and H_l g are formed as H y, H g plus the corrections, and after
+ * the J-th the updates are folded into H element by element in the order they occurred -- bitwise the H that
+ * applying them one at a time would have produced from the same q_l.  One read pass over H per iteration. */
+typedef struct {
+    int J, nd, ident;
+    double aid;
+    double *S, *Q; /* [J][n] */
+    double rho[64], cs[64];
+} bfgs_lazy;
+
+static void lazy_fold(int n, double *H, bfgs_lazy *L)
+{
+    size_t N = (size_t)n;
+    for (int b = 0; b < n; ++b)
+        for (int a = 0; a < n; ++a) {
+            double h = L->ident ? (a == b ? L->aid : 0.0) : H[b * N + a];
+            for (int l = 0; l < L->nd; ++l) {
+                const double *S = L->S + l * N, *Q = L->Q + l * N;
+                h = h - (L->rho[l] * Q[a]) * S[b] - (L->rho[l] * S[a]) * Q[b] + (L->cs[l] * S[a]) * S[b];
+            }
+            H[b * N + a] = h;
+        }
+    L->ident = 0;
+    L->nd = 0;
+}
+
+/* p = -H_new g, where H_new = H_cur updated with (s, y); first != 0: H_cur = a I (NO.f90:711-715) */
+static void lazy_direction(int n, double *H, bfgs_lazy *L, const double *s, const double *y, double rho, int first,
+                           double a, const double *g, double *p)
+{
+    size_t N = (size_t)n;
+    double *q = (double *)malloc(sizeof(double) * 2 * N), *w = q + N;
+    if (first) {
+        L->ident = 1;
+        L->aid = a;
+        L->nd = 0;
+    }
+    for (int i = 0; i < n; ++i) {
+        if (L->ident) {
+            q[i] = L->aid * y[i];
+            w[i] = L->aid * g[i];
+        } else {
+            double v = 0.0, u = 0.0;
+            for (int k = 0; k < n; ++k) {
+                v = v + H[k * N + i] * y[k];
+                u = u + H[k * N + i] * g[k];
+            }
+            q[i] = v;
+            w[i] = u;
+        }
+    }
+    for (int l = 0; l < L->nd; ++l) {
+        const double *S = L->S + l * N, *Q = L->Q + l * N;
+        const double sy = flo_dot(n, S, y), qy = flo_dot(n, Q, y), sg = flo_dot(n, S, g), qg = flo_dot(n, Q, g);
+        for (int i = 0; i < n; ++i) {
+            const double rq = L->rho[l] * Q[i], rs = L->rho[l] * S[i], cc = L->cs[l] * S[i];
+            q[i] = q[i] - rq * sy - rs * qy + cc * sy;
+            w[i] = w[i] - rq * sg - rs * qg + cc * sg;
+        }
+    }
+    const double t = flo_dot(n, y, q), cs = rho * rho * t + rho;
+    const double sg = flo_dot(n, s, g), qg = flo_dot(n, q, g);
+    for (int i = 0; i < n; ++i) p[i] = -(w[i] - (rho * q[i]) * sg - (rho * s[i]) * qg + (cs * s[i]) * sg);
+    memcpy(L->S + L->nd * N, s, sizeof(double) * N);
+    memcpy(L->Q + L->nd * N, q, sizeof(double) * N);
+    L->rho[L->nd] = rho;
+    L->cs[L->nd] = cs;
+    L->nd++;
+    if (L->nd == L->J) lazy_fold(n, H, L);
+    free(q);
+}
+
 /* one update of a column-major n x n inverse Hessian (rho computed here), for the tests of the
  * stand-alone GPU update kernels: form 0 = the reference's two matmuls, form 1 = rank-2 */
 void flo_bfgs_update(int n, double *H, const double *s, const double *y, int form)
@@ -835,6 +910,13 @@ void flo_bfgs(flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, flo_fdd_t fdd, double *x, 
     double *p = (double *)malloc(sizeof(double) * (4 * N + 2 * N * N));
     double *g = p + N, *s = g + N, *y = s + N, *U = y + N, *H = U + N * N;
     int info = 1;
+    bfgs_lazy L;
+    L.J = update_form >= 100 ? update_form - 100 : 0;
+    L.nd = 0;
+    L.ident = 0;
+    L.aid = 0.0;
+    L.S = L.J > 0 ? (double *)malloc(sizeof(double) * 2 * (size_t)L.J * N) : NULL;
+    L.Q = L.J > 0 ? L.S + (size_t)L.J * N : NULL;
     clamp_c(o, &c1, &c2);
     st_zero(st);
     initial_eval(f, fd, f_fd, &fnew, g, x, n, ctx, st);
@@ -874,8 +956,12 @@ void flo_bfgs(flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, flo_fdd_t fdd, double *x, 
             y[i] = g[i] - y[i];
         }
         rho = 1.0 / flo_dot(n, y, s);
-        bfgs_update(n, H, U, s, y, rho, 1, a, update_form);
-        neg_matvec(n, H, g, p);
+        if (L.J > 0) {
+            lazy_direction(n, H, &L, s, y, rho, 1, a, g, p);
+        } else {
+            bfgs_update(n, H, U, s, y, rho, 1, a, update_form);
+            neg_matvec(n, H, g, p);
+        }
         phidnew = flo_dot(n, g, p);
         a = 1.0;
     }
@@ -909,6 +995,8 @@ void flo_bfgs(flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, flo_fdd_t fdd, double *x, 
                     for (int c = 0; c < n; ++c)
                         for (int r = c; r < n; ++r) H[c * N + r] = U[c * N + r];
                     flo_syL2U(H, n);
+                    L.nd = 0; /* pending updates belong to the matrix that has just been replaced */
+                    L.ident = 0;
                     neg_matvec(n, H, g, p);
                     phidnew = flo_dot(n, g, p);
                     a = 1.0;
@@ -921,13 +1009,18 @@ void flo_bfgs(flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, flo_fdd_t fdd, double *x, 
                 y[k] = g[k] - y[k];
             }
             rho = 1.0 / flo_dot(n, y, s);
-            bfgs_update(n, H, U, s, y, rho, 0, 0.0, update_form);
-            neg_matvec(n, H, g, p);
+            if (L.J > 0) {
+                lazy_direction(n, H, &L, s, y, rho, 0, 0.0, g, p);
+            } else {
+                bfgs_update(n, H, U, s, y, rho, 0, 0.0, update_form);
+                neg_matvec(n, H, g, p);
+            }
             phidnew = flo_dot(n, g, p);
             a = 1.0;
         }
     }
 out:
+    free(L.S);
     free(p);
 }
 

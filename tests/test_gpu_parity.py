@@ -288,6 +288,8 @@ def _oracle_bfgs(kind, x0, d, b, form, mode, kw):
     T, E = NLO.reduction_geometry(n)
     o = _oracle_opts(O.BFGS, kw)
     o.exact_step = kw.get("ExactStep", 0)
+    if form == 1 and T * E >= 2048:  # n > 1024: the kernels defer the rank-2 updates, folding every 8th (form 100 + 8)
+        form = 108
     return O.solve_batch(O.BFGS, kind, x0, d=d, b=b, opts=o, use_ffd=bool(kw.get("f_fd", False)), bfgs_form=form,
                          sum_mode=mode, threads=T, ept=E)
 
@@ -387,9 +389,13 @@ def test_dposv_dpotri_batched_against_numpy():
                                        (O.ROSENBROCK, 10, {"Strong": False}), (O.ROSENBROCK, 7, {}),
                                        (O.ROSENBROCK, 130, {"MaxIteration": 150}), (O.DIAGQUAD, 96, {}),
                                        (O.DIAGQUAD, 300, {"MaxIteration": 100}), (O.ROSENBROCK, 600, {"MaxIteration": 40}),
-                                       (O.DIAGQUAD, 1100, {"MaxIteration": 12}), (O.ROSENBROCK, 2100, {"MaxIteration": 6})])
+                                       (O.DIAGQUAD, 1100, {"MaxIteration": 12}), (O.ROSENBROCK, 2100, {"MaxIteration": 19}),
+                                       (O.ROSENBROCK, 1500, {"MaxIteration": 9, "f_fd": True}),
+                                       (O.ROSENBROCK, 1200, {"ExactStep": 5, "MaxIteration": 12})])
 def test_bfgs_rank2_streaming_update_bitexact(kind, n, kw):
-    """GPU BFGS == oracle BFGS with the same rank-2 algebra (update_form 1), bit for bit, all geometries"""
+    """GPU BFGS == oracle BFGS with the same rank-2 algebra, bit for bit, all geometries: update_form 1 (H updated
+    every iteration) up to n = 1024, the deferred form beyond (pending updates as vectors, folded into H every 8th
+    iteration: across zero, one and two folds, and across an exact-Hessian refresh that drops pending updates)"""
     rng = np.random.default_rng(n)
     B = 3 if n < 1000 else 2
     if kind == O.ROSENBROCK:
