@@ -16,48 +16,87 @@ namespace fl {
 template <int NW, int EPT> struct Dense {
     using G = Geo<NW, EPT>;
     static constexpr int NPAD = G::NPAD;
-    static constexpr int UNR = 4;
     __device__ __forceinline__ static int row_of(int k) { return G::e0(k >> 1) + (k & 1); }
 
-    // A = L L^T in place (lower).  rowbuf: LDS [NPAD] doubles, slot: LDS [2] doubles.  Returns LAPACK's info.
+    // A = L L^T in place (lower).  rowbuf: LDS [>= BW*KT] doubles, slot: LDS [2 + BW] doubles.  Returns LAPACK's info.
+    // Left-looking, BW columns at a time: every earlier column is read ONCE per block of BW columns (its BW
+    // multipliers L(j0+u,k) come from LDS), then the block is finished column by column in registers.  Each
+    // element still sees  v = v - L(i,k) L(j,k)  for k = 0, 1, 2, ... in that order, so the factor is bitwise
+    // the one of the column-at-a-time sweep (and of the oracle's sequential sums).
+#ifndef FL_DENSE_BW
+#define FL_DENSE_BW 8 // measured: Newton n=256 x 4096: 143 k it/s (2), 254 k (4), 387 k (8); column-at-a-time 79 k
+#endif
+    // n <= 128 (EPT = 2): 4 -- the wider block costs the small BFGS kernels 70 VGPRs (4 -> 2 waves/SIMD) for nothing
+    static constexpr int BW = (EPT <= 2 && FL_DENSE_BW > 4) ? 4 : FL_DENSE_BW, KT = (NPAD / BW < 256) ? NPAD / BW : 256; // BW*KT <= NPAD doubles of LDS
+    static constexpr int UNR = BW; // columns of W^T W per sweep
     __device__ static int cholesky(double *A, int n, double *rowbuf, double *slot)
     {
         int info = 0;
-        for (int j = 0; j < n && info == 0; ++j) {
-            __syncthreads();
-            for (int k = threadIdx.x; k < j; k += G::T) rowbuf[k] = A[(size_t)k * NPAD + j]; // L(j,k), k<j
-            __syncthreads();
-            double v[EPT];
-            load_pad<NW, EPT>(A + (size_t)j * NPAD, v);
-            for (int k0 = 0; k0 < j; k0 += UNR) {
-                double c[UNR][EPT];
+        for (int j0 = 0; j0 < n && info == 0; j0 += BW) {
+            const int bw = (n - j0 < BW) ? n - j0 : BW;
+            double v[BW][EPT];
 #pragma unroll
-                for (int u = 0; u < UNR; ++u)
-                    if (k0 + u < j) load_pad<NW, EPT>(A + (size_t)(k0 + u) * NPAD, c[u]);
+            for (int u = 0; u < BW; ++u)
+                if (u < bw) load_pad<NW, EPT>(A + (size_t)(j0 + u) * NPAD, v[u]);
+            for (int kt = 0; kt < j0; kt += KT) {
+                const int kn = (j0 - kt < KT) ? j0 - kt : KT;
+                __syncthreads();
+                for (int i = threadIdx.x; i < kn * BW; i += G::T) { // rowbuf[u*KT + kk] = L(j0+u, kt+kk)
+                    const int kk = i / BW, u = i - kk * BW;
+                    rowbuf[u * KT + kk] = (u < bw) ? A[(size_t)(kt + kk) * NPAD + j0 + u] : 0.0;
+                }
+                __syncthreads();
+                for (int k0 = 0; k0 < kn; k0 += 2) {
+                    double c[2][EPT];
+                    load_pad<NW, EPT>(A + (size_t)(kt + k0) * NPAD, c[0]);
+                    if (k0 + 1 < kn) load_pad<NW, EPT>(A + (size_t)(kt + k0 + 1) * NPAD, c[1]);
 #pragma unroll
-                for (int u = 0; u < UNR; ++u)
-                    if (k0 + u < j) {
-                        const double ljk = rowbuf[k0 + u];
+                    for (int h = 0; h < 2; ++h) {
+                        if (k0 + h < kn) {
 #pragma unroll
-                        for (int r = 0; r < EPT; ++r) v[r] = v[r] - c[u][r] * ljk;
+                            for (int u = 0; u < BW; ++u) {
+                                const double l = rowbuf[u * KT + k0 + h];
+#pragma unroll
+                                for (int r = 0; r < EPT; ++r) v[u][r] = v[u][r] - c[h][r] * l;
+                            }
+                        }
                     }
+                }
             }
+            // the block itself: column j0+u is finished, then subtracted from the columns to its right
 #pragma unroll
-            for (int r = 0; r < EPT; ++r)
-                if (row_of(r) == j) slot[j & 1] = v[r];
-            __syncthreads();
-            const double piv = slot[j & 1];
-            if (!(piv > 0.0)) {
-                info = j + 1;
-                break;
-            }
-            const double ajj = sqrt(piv);
+            for (int u = 0; u < BW; ++u) {
+                if (u < bw && info == 0) {
+                    const int j = j0 + u;
+                    __syncthreads();
 #pragma unroll
-            for (int r = 0; r < EPT; ++r) {
-                const int i = row_of(r);
-                v[r] = (i == j) ? ajj : v[r] / ajj;
+                    for (int r = 0; r < EPT; ++r)
+                        if (row_of(r) == j) slot[0] = v[u][r];
+                    __syncthreads();
+                    const double piv = slot[0];
+                    if (!(piv > 0.0)) {
+                        info = j + 1;
+                    } else {
+                        const double ajj = sqrt(piv);
+#pragma unroll
+                        for (int r = 0; r < EPT; ++r) {
+                            const int i = row_of(r);
+                            v[u][r] = (i == j) ? ajj : v[u][r] / ajj;
+                            if (i > j && i < j0 + BW) slot[2 + (i - j0)] = v[u][r]; // L(j0+u', j) for the block's later columns
+                        }
+                        store_pad<NW, EPT>(A + (size_t)j * NPAD, v[u]);
+                        __syncthreads();
+#pragma unroll
+                        for (int u2 = 0; u2 < BW; ++u2) {
+                            if (u2 > u && u2 < bw) {
+                                const double l = slot[2 + u2];
+#pragma unroll
+                                for (int r = 0; r < EPT; ++r) v[u2][r] = v[u2][r] - v[u][r] * l;
+                            }
+                        }
+                    }
+                }
             }
-            store_pad<NW, EPT>(A + (size_t)j * NPAD, v);
         }
         __syncthreads();
         return info;
@@ -106,32 +145,65 @@ template <int NW, int EPT> struct Dense {
 
     // W = inverse of the lower factor, stored by ROWS: Wt[j*NPAD + c] = W(j,c).
     // W(j,:) = (e_j - sum_{k<j} L(j,k) W(k,:)) / L(j,j): each thread owns columns c, sums over k in order.
+    // BW rows at a time (every earlier row of W is read once per block; same order of operations per element).
     __device__ static void inverse_factor(const double *L, double *Wt, int n, double *rowbuf)
     {
-        for (int j = 0; j < n; ++j) {
-            __syncthreads();
-            for (int k = threadIdx.x; k <= j; k += G::T) rowbuf[k] = L[(size_t)k * NPAD + j]; // L(j,k), k<=j
-            __syncthreads();
-            double v[EPT];
+        for (int j0 = 0; j0 < n; j0 += BW) {
+            const int bw = (n - j0 < BW) ? n - j0 : BW;
+            double v[BW][EPT];
 #pragma unroll
-            for (int r = 0; r < EPT; ++r) v[r] = (row_of(r) == j) ? 1.0 : 0.0;
-            for (int k0 = 0; k0 < j; k0 += UNR) {
-                double w[UNR][EPT];
+            for (int u = 0; u < BW; ++u)
 #pragma unroll
-                for (int u = 0; u < UNR; ++u)
-                    if (k0 + u < j) load_pad<NW, EPT>(Wt + (size_t)(k0 + u) * NPAD, w[u]);
+                for (int r = 0; r < EPT; ++r) v[u][r] = (row_of(r) == j0 + u) ? 1.0 : 0.0;
+            for (int kt = 0; kt < j0; kt += KT) {
+                const int kn = (j0 - kt < KT) ? j0 - kt : KT;
+                __syncthreads();
+                for (int i = threadIdx.x; i < kn * BW; i += G::T) { // rowbuf[u*KT + kk] = L(j0+u, kt+kk)
+                    const int kk = i / BW, u = i - kk * BW;
+                    rowbuf[u * KT + kk] = (u < bw) ? L[(size_t)(kt + kk) * NPAD + j0 + u] : 0.0;
+                }
+                __syncthreads();
+                for (int k0 = 0; k0 < kn; k0 += 2) {
+                    double w[2][EPT];
+                    load_pad<NW, EPT>(Wt + (size_t)(kt + k0) * NPAD, w[0]);
+                    if (k0 + 1 < kn) load_pad<NW, EPT>(Wt + (size_t)(kt + k0 + 1) * NPAD, w[1]);
 #pragma unroll
-                for (int u = 0; u < UNR; ++u)
-                    if (k0 + u < j) {
-                        const double ljk = rowbuf[k0 + u];
+                    for (int h = 0; h < 2; ++h) {
+                        if (k0 + h < kn) {
 #pragma unroll
-                        for (int r = 0; r < EPT; ++r) v[r] = v[r] - ljk * w[u][r];
+                            for (int u = 0; u < BW; ++u) {
+                                const double l = rowbuf[u * KT + k0 + h];
+#pragma unroll
+                                for (int r = 0; r < EPT; ++r) v[u][r] = v[u][r] - l * w[h][r];
+                            }
+                        }
                     }
+                }
             }
-            const double ljj = rowbuf[j];
+            // inside the block: L(j0+u, j0+u') for u' <= u (BW x BW values)
+            __syncthreads();
+            for (int i = threadIdx.x; i < BW * BW; i += G::T) {
+                const int u = i / BW, u2 = i - u * BW;
+                rowbuf[i] = (u < bw && u2 <= u) ? L[(size_t)(j0 + u2) * NPAD + j0 + u] : 0.0;
+            }
+            __syncthreads();
 #pragma unroll
-            for (int r = 0; r < EPT; ++r) v[r] = (row_of(r) < n) ? v[r] / ljj : 0.0;
-            store_pad<NW, EPT>(Wt + (size_t)j * NPAD, v);
+            for (int u = 0; u < BW; ++u) {
+                if (u < bw) {
+#pragma unroll
+                    for (int u2 = 0; u2 < BW; ++u2) {
+                        if (u2 < u) {
+                            const double l = rowbuf[u * BW + u2];
+#pragma unroll
+                            for (int r = 0; r < EPT; ++r) v[u][r] = v[u][r] - l * v[u2][r];
+                        }
+                    }
+                    const double ljj = rowbuf[u * BW + u];
+#pragma unroll
+                    for (int r = 0; r < EPT; ++r) v[u][r] = (row_of(r) < n) ? v[u][r] / ljj : 0.0;
+                    store_pad<NW, EPT>(Wt + (size_t)(j0 + u) * NPAD, v[u]);
+                }
+            }
         }
         __syncthreads();
     }

@@ -12,10 +12,10 @@ __global__ __launch_bounds__(NW * 64) void dposv_kernel(int n, double *A_all, do
 {
     using D = Dense<NW, EPT>;
     constexpr int NPAD = D::NPAD;
-    __shared__ __attribute__((aligned(16))) double lds[NPAD + 2 + 2 * Reducer<NW>::NVMAX * NW];
+    __shared__ __attribute__((aligned(16))) double lds[NPAD + 16 + 2 * Reducer<NW>::NVMAX * NW]; // row buffer, pivot / block slots, reducer
     const int prob = blockIdx.x;
     double *A = A_all + (size_t)prob * n * NPAD;
-    Reducer<NW> R{lds + NPAD + 2, 0};
+    Reducer<NW> R{lds + NPAD + 16, 0};
     const int inf = D::cholesky(A, n, lds, lds + NPAD);
     if (inf == 0) {
         double b[EPT];
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(NW * 64) void dpotri_kernel(int n, double *A_all, d
 {
     using D = Dense<NW, EPT>;
     constexpr int NPAD = D::NPAD;
-    __shared__ __attribute__((aligned(16))) double lds[NPAD + 2];
+    __shared__ __attribute__((aligned(16))) double lds[NPAD + 16];
     const int prob = blockIdx.x;
     double *A = A_all + (size_t)prob * n * NPAD, *W = W_all + (size_t)prob * n * NPAD;
     const int inf = D::cholesky(A, n, lds, lds + NPAD);
