@@ -391,6 +391,7 @@ def test_dposv_dpotri_batched_against_numpy():
                                        (O.DIAGQUAD, 300, {"MaxIteration": 100}), (O.ROSENBROCK, 600, {"MaxIteration": 40}),
                                        (O.DIAGQUAD, 1100, {"MaxIteration": 12}), (O.ROSENBROCK, 2100, {"MaxIteration": 19}),
                                        (O.ROSENBROCK, 1500, {"MaxIteration": 9, "f_fd": True}),
+                                       (O.DIAGQUAD, 4096, {"MaxIteration": 17}),  # BASELINE config 4's size and family
                                        (O.ROSENBROCK, 1200, {"ExactStep": 5, "MaxIteration": 12})])
 def test_bfgs_rank2_streaming_update_bitexact(kind, n, kw):
     """GPU BFGS == oracle BFGS with the same rank-2 algebra, bit for bit, all geometries: update_form 1 (H updated

@@ -128,3 +128,30 @@ def test_fixture_file_agrees_with_pins():
         o = O.defaults(c2=0.45 if solver == O.CG else 0.9, method=1 if c.get("method") == "PR" else 0)
         r = O.solve_batch(solver, O.DIAGQUAD, np.zeros(n), d=d, b=np.sin(i), opts=o)
         assert _close(r["f"][0], c["f"]) and (r["nf"][0] + 1, r["ng"][0]) == (c["nf_plus_1"], c["ng"])
+
+
+def test_deferred_bfgs_form_agrees_with_the_reference_form():
+    """The kernels' deferred rank-2 form for n > 1024 (oracle update_form 100+J: pending updates kept as vectors,
+    folded into H every J-th iteration) is the same algorithm as the reference's two-matmul update (form 0, pinned
+    above) and the immediate rank-2 form (1): same minimiser, same objective, for every J, with and without an
+    exact-Hessian refresh in between."""
+    x0 = np.full((1, 10), -1.2)
+    x0[:, 1::2] = 1.0
+    ref0 = O.solve_batch(O.BFGS, O.ROSENBROCK, x0, opts=O.defaults(exact_step=0), bfgs_form=0)
+    assert ref0["f"][0] == 0.0 and np.all(ref0["x"][0] == 1.0)
+    for J in (1, 2, 3, 8, 16):
+        r = O.solve_batch(O.BFGS, O.ROSENBROCK, x0, opts=O.defaults(exact_step=0), bfgs_form=100 + J)
+        assert r["f"][0] <= 1e-25 and np.max(np.abs(r["x"][0] - 1.0)) <= 1e-12, J
+        assert abs(int(r["iters"][0]) - int(ref0["iters"][0])) <= 3
+        r5 = O.solve_batch(O.BFGS, O.ROSENBROCK, x0, opts=O.defaults(exact_step=5), bfgs_form=100 + J)
+        assert r5["f"][0] <= 1e-25 and np.max(np.abs(r5["x"][0] - 1.0)) <= 1e-12, J
+    rng = np.random.default_rng(3)
+    n = 64
+    d = 1.0 + 99.0 * np.arange(n) / (n - 1)
+    b = rng.uniform(-1, 1, n)
+    z = np.zeros((1, n))
+    o = O.defaults(exact_step=0, precision=1e-10)
+    r1 = O.solve_batch(O.BFGS, O.DIAGQUAD, z, d=d[None], b=b[None], opts=o, bfgs_form=1)
+    r8 = O.solve_batch(O.BFGS, O.DIAGQUAD, z, d=d[None], b=b[None], opts=o, bfgs_form=108)
+    assert abs(r1["f"][0] - r8["f"][0]) <= 1e-12 * abs(r1["f"][0])
+    assert np.linalg.norm(r1["x"][0] - r8["x"][0]) <= 1e-8 * max(1.0, np.linalg.norm(r1["x"][0]))
