@@ -373,20 +373,26 @@ static HostObjective host_objective(f_cb f, fd_cb fd, ffd_cb f_fd)
 // 981, 1067, 1258) -- central differences; MKL is closed and the reference does not state its step rule, so this
 // branch is "parity unpinned" (DESIGN.md).  Here: column j = (f'(x + h e_j) - f'(x - h e_j)) / (2h),
 // h = 1e-8 * max(1, |x_j|), 2n gradient calls per Hessian like djacobi.
-static std::function<void(double *, const double *, int)> central_difference_hessian(fd_cb fd)
+static std::function<void(double *, const double *, int)>
+central_difference_hessian(std::function<void(double *, const double *, int)> grad)
 {
-    return [fd](double *H, const double *x, int n) {
+    return [grad](double *H, const double *x, int n) {
         std::vector<double> xp(x, x + n), gp(n), gm(n);
         for (int j = 0; j < n; ++j) {
             const double h = 1e-8 * std::fmax(1.0, std::fabs(x[j]));
             xp[j] = x[j] + h;
-            fd(gp.data(), xp.data(), n);
+            grad(gp.data(), xp.data(), n);
             xp[j] = x[j] - h;
-            fd(gm.data(), xp.data(), n);
+            grad(gm.data(), xp.data(), n);
             xp[j] = x[j];
             for (int i = 0; i < n; ++i) H[(size_t)j * n + i] = (gp[i] - gm[i]) / (2.0 * h);
         }
     };
+}
+static std::function<void(double *, const double *, int)> central_difference_hessian(fd_cb fd)
+{
+    return central_difference_hessian(
+        std::function<void(double *, const double *, int)>([fd](double *g, const double *x, int n) { fd(g, x, n); }));
 }
 
 static int legacy_solve(int solver, const char *name, const HostObjective &ob, double *x, int n, const fl_options &o,
@@ -670,8 +676,6 @@ void __nonlinearoptimization_MOD_augmentedlagrangian(f_cb f, fd_cb fd, c_cb c, c
                                                      const int *ExactStep, const int *Memory, const char *Method,
                                                      ffd_cb f_fd, FL_LEGACY_COMMON, int len_solver, int len_method)
 {
-    (void)fdd;
-    (void)cdd;
     const int n = *N, m = *M;
     std::string solver = UnconstrainedSolver ? std::string(UnconstrainedSolver, (size_t)len_solver) : "BFGS";
     while (!solver.empty() && solver.back() == ' ') solver.pop_back();
@@ -680,7 +684,8 @@ void __nonlinearoptimization_MOD_augmentedlagrangian(f_cb f, fd_cb fd, c_cb c, c
     if (solver == "LBFGS") sv = FL_SOLVER_LBFGS;
     else if (solver == "ConjugateGradient") sv = FL_SOLVER_CG;
     else if (solver == "BFGS") sv = FL_SOLVER_BFGS;
-    else { // NO.f90:2186 (NewtonRaphson: not on the device path)
+    else if (solver == "NewtonRaphson") sv = FL_SOLVER_NEWTON;
+    else { // NO.f90:2186
         std::printf(" Program abort: unsupported unconstrained solver %s\n", solver.c_str());
         return;
     }
@@ -689,7 +694,7 @@ void __nonlinearoptimization_MOD_augmentedlagrangian(f_cb f, fd_cb fd, c_cb c, c
     if (!WolfeConst2) o.wolfe_c2 = (sv == FL_SOLVER_CG) ? 0.45 : 0.9; // NO.f90:2053-2062
     if (Memory) o.memory = *Memory;
     o.fused_f_fd = 1; // the inner solver always receives f_fd=L_Ld (NO.f90:2134, 2153, 2171)
-    o.exact_step = 0; // no Ldd on the device path: quasi-Newton branch
+    o.exact_step = (sv == FL_SOLVER_BFGS) ? (ExactStep ? *ExactStep : 20) : 0; // freq, NO.f90:2044-2045
     if (sv == FL_SOLVER_CG) {
         const int mth = cg_method_of(Method, Method ? len_method : 0);
         if (mth < 0) {
@@ -698,8 +703,6 @@ void __nonlinearoptimization_MOD_augmentedlagrangian(f_cb f, fd_cb fd, c_cb c, c
         }
         o.cg_method = mth;
     }
-    if (sv == FL_SOLVER_BFGS && (ExactStep ? *ExactStep : 20) > 0 && warn)
-        std::printf(" BFGS (MI355X): exact Hessian refresh is not available on the device path; quasi-Newton updates only\n");
     const int maxit = MaxIteration ? *MaxIteration : 1000;
     const double tol = Precision ? *Precision : 1e-15, incrmt = Increment ? *Increment : 1.05;
     std::vector<double> lambda(m, 0.0), cx(m), cdx((size_t)n * m), v(m);
@@ -746,7 +749,33 @@ void __nonlinearoptimization_MOD_augmentedlagrangian(f_cb f, fd_cb fd, c_cb c, c
         }
         ldx(Ldx);
     };
-    const char *names[] = {"steepest descent", "conjugate gradient", "L-BFGS", "BFGS"};
+    // Ldd (NO.f90:2229-2240), handed to NewtonRaphson / BFGS when the caller gave fdd AND cdd; as written there:
+    // Lddx = f'' + sum_k c''_k (miu c_k - lambda_k) + matmul(cdx, transpose(cdx)) -- no miu on the last term.
+    // Without them the inner solver differentiates Ld numerically (the reference: MKL djacobi; here central differences).
+    std::vector<double> cddx, vk(m);
+    if (sv == FL_SOLVER_NEWTON || (sv == FL_SOLVER_BFGS && o.exact_step > 0)) {
+        if (fdd && cdd) {
+            cddx.resize((size_t)n * n * m);
+            ob.fdd = [&, fdd, cdd](double *Lddx, const double *xx, int nn) {
+                (void)fdd(Lddx, xx, nn);
+                (void)cdd(cddx.data(), xx, m, nn); // cddx(N,N,M), column-major
+                c(cx.data(), xx, m, nn);
+                cd(cdx.data(), xx, m, nn);
+                for (int k = 0; k < m; ++k) cx[k] = miu * cx[k] - lambda[k]; // cx=miu*cx-lambda
+                for (int i = 0; i < nn; ++i)
+                    for (int j = 0; j < nn; ++j) {
+                        double t = 0.0; // Lddxtemp(j,i)=sum_k cddx(i,j,k)*cx(k)
+                        for (int k = 0; k < m; ++k) t = t + cddx[(size_t)k * nn * nn + (size_t)j * nn + i] * cx[k];
+                        double cc = 0.0; // matmul(cdx,transpose(cdx))(j,i)
+                        for (int k = 0; k < m; ++k) cc = cc + cdx[(size_t)k * nn + j] * cdx[(size_t)k * nn + i];
+                        Lddx[(size_t)i * nn + j] = Lddx[(size_t)i * nn + j] + t + cc;
+                    }
+            };
+        } else {
+            ob.fdd = central_difference_hessian(ob.fd);
+        }
+    }
+    const char *names[] = {"steepest descent", "conjugate gradient", "L-BFGS", "BFGS", "Newton-Raphson"};
     int it = 1;
     for (; it <= maxit; ++it) {
         if (legacy_solve(sv, names[sv], ob, x, n, o, warn) < 0) return;

@@ -17,7 +17,7 @@
 !New: LBFGS_batched / ConjugateGradient_batched -- batches of independent problems with
 !device-resident data and built-in objectives (include/fl_nlopt.h).
 !  NewtonRaphson     <- reference NonlinearOptimization.f90:1026 (without fdd: central differences of fd)
-!  AugmentedLagrangian <- reference NonlinearOptimization.f90:2005 (inner solvers LBFGS / ConjugateGradient / BFGS)
+!  AugmentedLagrangian <- reference NonlinearOptimization.f90:2005 (inner solvers LBFGS / ConjugateGradient / BFGS / NewtonRaphson)
 !  Wolfe, Wolfe_fdwithf, StrongWolfe, StrongWolfe_fdwithf <- reference NonlinearOptimization.f90:1286, 1373, 1462, 1582
 !Not provided (SURVEY.md sections 2, 8f): TrustRegion (MKL RCI), LagrangianMultiplier.
 module NonlinearOptimization
@@ -324,8 +324,8 @@ contains
 
     !Augmented Lagrangian multiplier method (reference NonlinearOptimization.f90:2005-2241): equality constraints
     !c(x)=0 with  subroutine c(c(x),x,M,N),  subroutine cd(c'(x),x,M,N) (c'(x) is N x M).  Inner solvers on the device:
-    !'LBFGS', 'ConjugateGradient', 'BFGS' (default, quasi-Newton branch); the wrappers L, Ld (2193-2228) are evaluated on
-    !the host next to the caller's f, fd, c, cd.  fdd / cdd are accepted for keyword compatibility and not used
+    !'LBFGS', 'ConjugateGradient', 'BFGS' (default), 'NewtonRaphson'; the wrappers L, Ld, Ldd (2193-2240) are evaluated on
+    !the host next to the caller's f, fd, c, cd (fdd, cdd); without fdd & cdd the Hessian of L is differentiated numerically
     subroutine AugmentedLagrangian(f, fd, c, cd, x, N, M, &
     UnconstrainedSolver, lambda0, miu0, &
     fdd, cdd, ExactStep, Memory, Method, &

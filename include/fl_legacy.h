@@ -18,9 +18,9 @@
  * them; all solver arithmetic runs on the GPU (reverse communication, fl_nlopt.h: fl_rci_*).
  * x is the only result (in/out), warnings go to stdout when Warning is true, like the reference.
  * Differences: an unknown Method prints the reference's message and returns instead of `stop`;
- * AugmentedLagrangian: 'LBFGS', 'ConjugateGradient', 'BFGS' inner solvers ('NewtonRaphson' is refused with
- * the reference's "unsupported unconstrained solver" message); the wrappers L, Ld, L_Ld that compose the
- * caller's f, fd, c, cd (NO.f90:2193-2228) run on the host next to those callbacks, every inner solve on the GPU.
+ * AugmentedLagrangian: every inner solver of the reference's menu ('LBFGS', 'ConjugateGradient', 'BFGS',
+ * 'NewtonRaphson'; NO.f90:2074-2185); the wrappers L, Ld, L_Ld, Ldd that compose the caller's f, fd, fdd, c, cd, cdd
+ * (NO.f90:2193-2240) run on the host next to those callbacks, every inner solve on the GPU.
  * NewtonRaphson and BFGS with ExactStep > 0 call the caller's fdd on the host and ship the Hessian to the GPU
  * (Cholesky solve / inverse there); without fdd the reference calls MKL djacobi (closed, step rule unpublished):
  * here central differences of the caller's fd, h = 1e-8 max(1,|x_j|), 2n gradient calls per Hessian -- same

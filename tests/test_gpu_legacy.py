@@ -415,3 +415,52 @@ def test_public_line_searchers_bitexact(n):
             assert a.value == ao.value and fx.value == fo.value, (name, trial)
             assert np.array_equal(x, xo) and np.array_equal(fdx, go), (name, trial)
             assert cnt["f"] + cnt["f_fd"] == nf.value and cnt["fd"] + cnt["f_fd"] == ng.value, (name, trial)
+
+
+@pytest.mark.parametrize("solver,with_hessians,exact", [(b"NewtonRaphson", True, 0), (b"NewtonRaphson", False, 0),
+                                                        (b"BFGS", True, 5), (b"BFGS", False, 20), (b"BFGS", False, 0)])
+def test_legacy_augmented_lagrangian_dense_inner_solvers(solver, with_hessians, exact):
+    """AugmentedLagrangian with UnconstrainedSolver = 'NewtonRaphson' / 'BFGS' (NO.f90:2074-2149): with fdd and cdd
+    the inner solver receives Ldd (NO.f90:2229-2240, composed on the host next to the callbacks), without them the
+    Hessian of the Lagrangian comes from central differences of Ld (the reference: MKL djacobi).  Quartic, dim 10,
+    unit sphere: |x| - 1 close to 0 and x a constrained stationary point (f' parallel to x)."""
+    FL = _fl()
+    n, m = 10, 1
+    rng = np.random.default_rng(3)
+    x0 = rng.random(n)
+    f, fd, ffd, cnt, (T, E), P = _callbacks(O.QUARTIC, n)
+    lib = O.lib()
+    dp = C.POINTER(C.c_double)
+    lib.flo_prob_c.argtypes = [dp, dp, C.c_int, C.c_int, C.c_void_p]
+    lib.flo_prob_cd.argtypes = [dp, dp, C.c_int, C.c_int, C.c_void_p]
+    lib.flo_prob_fdd.argtypes = [dp, dp, C.c_int, C.c_void_p]
+    c = C_CB(lambda cx, x, M, N: lib.flo_prob_c(cx, x, M[0], N[0], None))
+    cd = C_CB(lambda cdx, x, M, N: lib.flo_prob_cd(cdx, x, M[0], N[0], None))
+
+    def fdd_py(H, x, dim):
+        lib.flo_prob_fdd(H, x, dim[0], C.byref(P))
+        return 0
+
+    def cdd_py(cddx, x, M, N):  # c = x.x - 1: c'' = 2 I
+        nn = N[0]
+        for i in range(nn * nn):
+            cddx[i] = 0.0
+        for i in range(nn):
+            cddx[i * nn + i] = 2.0
+        return 0
+    CDD_CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int))
+    fdd, cdd = FDD_CB(fdd_py), CDD_CB(cdd_py)
+    x = x0.copy()
+    N_, M_ = C.c_int(n), C.c_int(m)
+    lam0 = np.zeros(m)
+    miu0 = C.c_double(1.0)
+    es, mem = C.c_int(exact), C.c_int(10)
+    vals, refs = _common(precision=1e-8, maxit=60)
+    FL.__nonlinearoptimization_MOD_augmentedlagrangian(f, fd, c, cd, x.ctypes.data_as(dp), C.byref(N_), C.byref(M_), solver,
+                                                       lam0.ctypes.data_as(dp), C.byref(miu0), fdd if with_hessians else None,
+                                                       cdd if with_hessians else None, C.byref(es), C.byref(mem), b"DY", None,
+                                                       *refs, C.c_int(len(solver)), C.c_int(2))
+    assert abs(np.linalg.norm(x) - 1.0) < 1e-7
+    g = 4.0 * x ** 3
+    lam = (g @ x) / (2.0 * x @ x)  # f' = lambda c' at a constrained stationary point
+    assert np.linalg.norm(g - lam * 2.0 * x) < 1e-5
