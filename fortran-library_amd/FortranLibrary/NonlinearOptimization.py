@@ -157,6 +157,7 @@ FL.fl_workspace_bytes_for.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(Optio
 FL.fl_workspace_bytes_for.restype = C.c_size_t
 FL.fl_newton_raphson_batched.argtypes = FL.fl_lbfgs_batched.argtypes
 FL.fl_dposv_batched.argtypes = [C.c_int, C.c_int, _dp, _dp, _ip, _vp]
+FL.fl_dsysv_batched.argtypes = [C.c_int, C.c_int, _dp, _dp, _ip, _vp]
 FL.fl_dpotri_batched.argtypes = [C.c_int, C.c_int, _dp, _dp, _ip, _vp]
 NEWTON_ = 4
 
@@ -188,6 +189,16 @@ def dposv(A, b):
     B, n = b.shape
     info = torch.empty(B, dtype=torch.int32, device=b.device)
     _check(FL.fl_dposv_batched(B, n, _ptr(A), _ptr(b), _ptr(info), _stream()), "fl_dposv_batched")
+    return info
+
+
+def dsysv(A, b):
+    """My_dsysv for a batch: A [batch, n, ld] column-major symmetric INDEFINITE, lower triangle referenced
+    (destroyed), b [batch, n] -> solution.  Returns info [batch] (0 = solved)."""
+    import torch
+    B, n = b.shape
+    info = torch.empty(B, dtype=torch.int32, device=b.device)
+    _check(FL.fl_dsysv_batched(B, n, _ptr(A), _ptr(b), _ptr(info), _stream()), "fl_dsysv_batched")
     return info
 
 

@@ -42,6 +42,125 @@ __global__ __launch_bounds__(NW * 64) void dpotri_kernel(int n, double *A_all, d
     if (threadIdx.x == 0 && info) info[prob] = inf;
 }
 
+// My_dsysv (LinearAlgebra.f90:695-703: LAPACK dsysv 'L', symmetric indefinite solve) for the KKT systems of
+// LagrangianMultiplier (NO.f90:1950-1993).  LAPACK factorises with Bunch-Kaufman pivoting inside closed MKL; what
+// is restated here is the solve itself -- Gaussian elimination with partial pivoting on the matrix the lower
+// triangle defines, rows never moved (a row is "done" once it has been a pivot), right-hand side carried along,
+// back substitution in axpy form.  Every element sees its updates in elimination order: the oracle's flo_dsysv
+// replays it bit for bit.  One workgroup per system; O(n^3) streamed through L2/HBM -- sized for N+M of a few
+// hundred, not a LAPACK replacement.
+template <int NW, int EPT>
+__global__ __launch_bounds__(NW * 64) void dsysv_kernel(int n, double *A_all, double *b_all, int32_t *info)
+{
+    using G = Geo<NW, EPT>;
+    constexpr int NPAD = G::NPAD, T = G::T;
+    __shared__ double redv[T];
+    __shared__ int redi[T];
+    __shared__ int piv[NPAD];
+    __shared__ double bc[2];
+    const int prob = blockIdx.x, tid = threadIdx.x;
+    double *A = A_all + (size_t)prob * n * NPAD;
+    double *bu = b_all + (size_t)prob * n;
+    auto row_of = [&](int r) { return G::e0(r >> 1) + (r & 1); };
+    // the upper triangle from the lower one (dsysv 'L' references the lower triangle only)
+    for (int j = 1; j < n; ++j) {
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) {
+            const int i = row_of(r);
+            if (i < j) A[(size_t)j * NPAD + i] = A[(size_t)i * NPAD + j];
+        }
+    }
+    __syncthreads();
+    double b[EPT];
+    int pstep[EPT]; // elimination step at which the row was the pivot (n = not yet)
+    load_user<NW, EPT>(bu, n, b);
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) pstep[r] = n;
+    int inf = 0;
+    for (int k = 0; k < n; ++k) {
+        double col[EPT];
+        load_pad<NW, EPT>(A + (size_t)k * NPAD, col);
+        double bv = -1.0;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) {
+            const int i = row_of(r);
+            if (i < n && pstep[r] == n) {
+                const double v = fabs(col[r]);
+                if (v > bv || (v == bv && i < bi)) {
+                    bv = v;
+                    bi = i;
+                }
+            }
+        }
+        redv[tid] = bv;
+        redi[tid] = bi;
+        __syncthreads();
+        for (int s2 = T / 2; s2 > 0; s2 >>= 1) {
+            if (tid < s2) {
+                const double v2 = redv[tid + s2];
+                const int i2 = redi[tid + s2];
+                if (v2 > redv[tid] || (v2 == redv[tid] && i2 < redi[tid])) {
+                    redv[tid] = v2;
+                    redi[tid] = i2;
+                }
+            }
+            __syncthreads();
+        }
+        const double best = redv[0];
+        const int p = redi[0];
+        if (!(best > 0.0)) { // exactly singular (or NaN): LAPACK's info > 0
+            inf = k + 1;
+            break;
+        }
+        if (tid == 0) piv[k] = p;
+#pragma unroll
+        for (int r = 0; r < EPT; ++r)
+            if (row_of(r) == p) {
+                bc[0] = col[r];
+                bc[1] = b[r];
+                pstep[r] = k;
+            }
+        __syncthreads();
+        const double apk = bc[0], bp = bc[1];
+        double l[EPT];
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) {
+            const bool live = (row_of(r) < n) && pstep[r] == n;
+            l[r] = live ? col[r] / apk : 0.0;
+            if (live) b[r] = b[r] - l[r] * bp;
+        }
+        for (int j = k + 1; j < n; ++j) {
+            double c[EPT];
+            double *cj = A + (size_t)j * NPAD;
+            load_pad<NW, EPT>(cj, c);
+            const double apj = cj[p];
+#pragma unroll
+            for (int r = 0; r < EPT; ++r)
+                if (l[r] != 0.0) c[r] = c[r] - l[r] * apj;
+            store_pad<NW, EPT>(cj, c);
+        }
+        __syncthreads(); // the next pivot row is read by every thread after all updates of this step
+    }
+    if (inf == 0) {
+        for (int k = n - 1; k >= 0; --k) { // x_k = b_p / A(p,k); rows that were pivots earlier: b_i -= A(i,k) x_k
+            const int p = piv[k];
+            double col[EPT];
+            load_pad<NW, EPT>(A + (size_t)k * NPAD, col);
+#pragma unroll
+            for (int r = 0; r < EPT; ++r)
+                if (row_of(r) == p) bc[k & 1] = b[r] / col[r];
+            __syncthreads();
+            const double xk = bc[k & 1];
+#pragma unroll
+            for (int r = 0; r < EPT; ++r)
+                if (pstep[r] < k) b[r] = b[r] - col[r] * xk;
+            if (tid == 0) bu[k] = xk;
+        }
+    }
+    if (tid == 0 && info) info[prob] = inf;
+}
+
 } // namespace fl
 
 extern "C" {
@@ -78,6 +197,18 @@ int fl_dpotri_batched(int batch, int n, double *A_dev, double *work_dev, int32_t
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FL_ERR_NO_DEVICE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     FL_GEO_DISPATCH(dpotri_kernel, n, A_dev, work_dev, info_dev);
+    return hipGetLastError() == hipSuccess ? FL_OK : FL_ERR_NO_DEVICE;
+}
+
+int fl_dsysv_batched(int batch, int n, double *A_dev, double *b_dev, int32_t *info_dev, void *stream)
+{
+    if (!A_dev || !b_dev || batch <= 0 || n <= 0) return FL_ERR_INVALID_ARGUMENT;
+    int threads = 0, ept = 0;
+    if (n > 4096 || fl_reduction_geometry(n, &threads, &ept) != FL_OK) return FL_ERR_UNSUPPORTED_SIZE;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FL_ERR_NO_DEVICE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    FL_GEO_DISPATCH(dsysv_kernel, n, A_dev, b_dev, info_dev);
     return hipGetLastError() == hipSuccess ? FL_OK : FL_ERR_NO_DEVICE;
 }
 

@@ -888,4 +888,83 @@ void nonlinearoptimization_mp_strongwolfe_fdwithf_(const double *c1, const doubl
     __nonlinearoptimization_MOD_strongwolfe_fdwithf(c1, c2, f, fd, f_fd, x, a, p, fx, phid0, fdx, dim, Increment);
 }
 
+// subroutine LagrangianMultiplier(fd,fdd,c,cd,cdd,x,lambda,N,M,Warning,MaxIteration,Precision)  NO.f90:1950-1993:
+// Newton iteration on the KKT system of L = f - lambda.c.  The caller's callbacks and the assembly of -L', L''
+// (NO.f90:1972-1981: compositions of their outputs) run on the host; the (N+M)-dimensional symmetric indefinite
+// solve My_dsysv (NO.f90:1984) runs on the GPU (fl_dsysv_batched).
+void __nonlinearoptimization_MOD_lagrangianmultiplier(fd_cb fd, fdd_cb fdd, c_cb c, cd_cb cd, cdd_cb cdd, double *x,
+                                                      double *lambda, const int *N, const int *M,
+                                                      const int32_t *Warning, const int *MaxIteration,
+                                                      const double *Precision)
+{
+    const int n = *N, m = *M, dim = n + m;
+    const int warn = warn_of(Warning), maxit = MaxIteration ? *MaxIteration : 1000;
+    const double tol = Precision ? *Precision * *Precision : 1e-30;
+    int threads = 0, ept = 0;
+    if (dim > 4096 || fl_reduction_geometry(dim, &threads, &ept) != FL_OK) {
+        std::fprintf(stderr, "FortranLibrary(MI355X) LagrangianMultiplier: N+M = %d beyond the dense solver (4096)\n", dim);
+        return;
+    }
+    const size_t ld = (size_t)threads * ept;
+    std::vector<double> mLd(dim), cx(m), cdx((size_t)n * m), cddx((size_t)n * n * m), H((size_t)n * n), Ldd((size_t)dim * ld);
+    double *Ad = nullptr, *bd = nullptr;
+    int32_t *infod = nullptr;
+    bool ok = hipMalloc((void **)&Ad, sizeof(double) * dim * ld) == hipSuccess &&
+              hipMalloc((void **)&bd, sizeof(double) * dim) == hipSuccess &&
+              hipMalloc((void **)&infod, sizeof(int32_t)) == hipSuccess;
+    auto minus_gradient = [&]() { // minusLd(1:N)=matmul(cdx,lambda)-f'(x); minusLd(N+1:dim)=cx; returns its square norm
+        fd(mLd.data(), x, n);
+        c(cx.data(), x, m, n);
+        cd(cdx.data(), x, m, n);
+        for (int i = 0; i < n; ++i) {
+            double t = 0.0;
+            for (int k = 0; k < m; ++k) t = t + cdx[(size_t)k * n + i] * lambda[k];
+            mLd[i] = t - mLd[i];
+        }
+        for (int k = 0; k < m; ++k) mLd[n + k] = cx[k];
+        double nrm = 0.0;
+        for (int i = 0; i < dim; ++i) nrm = nrm + mLd[i] * mLd[i];
+        return nrm;
+    };
+    int it = 1;
+    for (; ok && it <= maxit; ++it) {
+        if (minus_gradient() < tol) break; // Converged
+        (void)fdd(H.data(), x, n);
+        (void)cdd(cddx.data(), x, m, n);
+        std::fill(Ldd.begin(), Ldd.end(), 0.0);
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < n; ++i) { // Ldd(i,1:N)=Ldd(i,1:N)-matmul(cddx(i,:,:),lambda)
+                double t = 0.0;
+                for (int k = 0; k < m; ++k) t = t + cddx[(size_t)k * n * n + (size_t)j * n + i] * lambda[k];
+                Ldd[(size_t)j * ld + i] = H[(size_t)j * n + i] - t;
+            }
+        for (int k = 0; k < m; ++k)
+            for (int j = 0; j < n; ++j) Ldd[(size_t)j * ld + n + k] = -cdx[(size_t)k * n + j]; // -transpose(cdx)
+        int32_t info = 0;
+        ok = hipMemcpy(Ad, Ldd.data(), sizeof(double) * dim * ld, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(bd, mLd.data(), sizeof(double) * dim, hipMemcpyHostToDevice) == hipSuccess &&
+             fl_dsysv_batched(1, dim, Ad, bd, infod, nullptr) == FL_OK &&
+             hipMemcpy(&info, infod, sizeof info, hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(mLd.data(), bd, sizeof(double) * dim, hipMemcpyDeviceToHost) == hipSuccess;
+        if (!ok || info != 0) break;
+        for (int i = 0; i < n; ++i) x[i] = x[i] + mLd[i];
+        for (int k = 0; k < m; ++k) lambda[k] = lambda[k] + mLd[n + k];
+    }
+    if (!ok) std::fprintf(stderr, "FortranLibrary(MI355X) LagrangianMultiplier: HIP error\n");
+    if (ok && it > maxit && warn) {
+        std::printf(" Failed Lagrangian multiplier: max iteration exceeded!\n");
+        std::printf(" Euclidean norm of Lagrangian gradient = %24.16E\n", sqrt(minus_gradient()));
+    }
+    if (Ad) (void)hipFree(Ad);
+    if (bd) (void)hipFree(bd);
+    if (infod) (void)hipFree(infod);
+}
+void nonlinearoptimization_mp_lagrangianmultiplier_(fd_cb fd, fdd_cb fdd, c_cb c, cd_cb cd, cdd_cb cdd, double *x,
+                                                    double *lambda, const int *N, const int *M, const int32_t *Warning,
+                                                    const int *MaxIteration, const double *Precision)
+{
+    __nonlinearoptimization_MOD_lagrangianmultiplier(fd, fdd, c, cd, cdd, x, lambda, N, M, Warning, MaxIteration,
+                                                     Precision);
+}
+
 } // extern "C"

@@ -19,7 +19,8 @@
 !  NewtonRaphson     <- reference NonlinearOptimization.f90:1026 (without fdd: central differences of fd)
 !  AugmentedLagrangian <- reference NonlinearOptimization.f90:2005 (inner solvers LBFGS / ConjugateGradient / BFGS / NewtonRaphson)
 !  Wolfe, Wolfe_fdwithf, StrongWolfe, StrongWolfe_fdwithf <- reference NonlinearOptimization.f90:1286, 1373, 1462, 1582
-!Not provided (SURVEY.md sections 2, 8f): TrustRegion (MKL RCI), LagrangianMultiplier.
+!  LagrangianMultiplier <- reference NonlinearOptimization.f90:1950
+!Not provided (SURVEY.md sections 2, 8f): TrustRegion (MKL RCI).
 module NonlinearOptimization
     use iso_c_binding
     implicit none
@@ -109,6 +110,14 @@ module NonlinearOptimization
             integer(c_int),intent(in)::dim
             type(c_ptr),value::Increment
         end subroutine flc_stronglinesearch
+        subroutine flc_lagrangianmultiplier(fd,fdd,c,cd,cdd,x,lambda,N,M,Warning,MaxIteration,Precision)&
+        bind(C,name='__nonlinearoptimization_MOD_lagrangianmultiplier')
+            import
+            type(c_funptr),value::fd,fdd,c,cd,cdd
+            real(c_double)::x(*),lambda(*)
+            integer(c_int),intent(in)::N,M
+            type(c_ptr),value::Warning,MaxIteration,Precision
+        end subroutine flc_lagrangianmultiplier
         subroutine fl_default_options(opt,solver) bind(C,name='fl_default_options')
             import
             type(fl_options),intent(out)::opt
@@ -321,6 +330,27 @@ contains
         pfdd=c_null_funptr; if(present(fdd)) pfdd=c_funloc(fdd)
         call flc_newtonraphson(c_funloc(f),c_funloc(fd),x,dim,pfdd,pf_fd,p(1),p(2),p(3),p(4),p(5),p(6),p(7),p(8))
     end subroutine NewtonRaphson
+
+    !Lagrangian multiplier method (reference NonlinearOptimization.f90:1950-1993): Newton iteration on the KKT system;
+    !on input lambda is an initial guess of the multipliers, on exit the solution.  fd, fdd, c, cd, cdd are evaluated on
+    !the host, the (N+M)-dimensional symmetric indefinite solve (My_dsysv) runs on the device
+    subroutine LagrangianMultiplier(fd, fdd, c, cd, cdd, x, lambda, N, M, &
+    Warning, MaxIteration, Precision)
+        external::fd,c,cd; integer,external::fdd,cdd
+        integer,intent(in)::N,M
+        real*8,dimension(N),intent(inout)::x; real*8,dimension(M),intent(inout)::lambda
+        logical,intent(in),optional::Warning
+        integer,intent(in),optional::MaxIteration
+        real*8,intent(in),optional::Precision
+        integer(c_int32_t),target::lw
+        integer(c_int),target::lmax
+        real(c_double),target::lp
+        type(c_ptr)::pw,pm,pp
+        pw=c_null_ptr; if(present(Warning)) then; lw=merge(1,0,Warning); pw=c_loc(lw); end if
+        pm=c_null_ptr; if(present(MaxIteration)) then; lmax=MaxIteration; pm=c_loc(lmax); end if
+        pp=c_null_ptr; if(present(Precision)) then; lp=Precision; pp=c_loc(lp); end if
+        call flc_lagrangianmultiplier(c_funloc(fd),c_funloc(fdd),c_funloc(c),c_funloc(cd),c_funloc(cdd),x,lambda,N,M,pw,pm,pp)
+    end subroutine LagrangianMultiplier
 
     !Augmented Lagrangian multiplier method (reference NonlinearOptimization.f90:2005-2241): equality constraints
     !c(x)=0 with  subroutine c(c(x),x,M,N),  subroutine cd(c'(x),x,M,N) (c'(x) is N x M).  Inner solvers on the device:

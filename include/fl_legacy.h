@@ -11,6 +11,8 @@
  *   __nonlinearoptimization_MOD_newtonraphson            cpp/NonlinearOptimization.hpp:344-358   (NO.f90:1026)
  *   __nonlinearoptimization_MOD_augmentedlagrangian      cpp/NonlinearOptimization.hpp:367-392   (NO.f90:2005)
  *   __nonlinearoptimization_MOD_lbfgs                    (Fortran only in the reference)          (NO.f90:398)
+ *   __nonlinearoptimization_MOD_lagrangianmultiplier     (Fortran only in the reference)          (NO.f90:1950)
+ *   __nonlinearoptimization_MOD_{wolfe,strongwolfe}[_fdwithf]  (Fortran only in the reference)     (NO.f90:1286-1698)
  *   nonlinearoptimization_mp_*_                          the ifort manglings, hpp:11-123
  * Conventions are the reference's (cpp/README.md:11-18): every argument by reference, an absent
  * Fortran optional = NULL, logical = 4-byte integer (nonzero = true), character(*) = pointer plus a
@@ -117,6 +119,17 @@ void nonlinearoptimization_mp_strongwolfe_fdwithf_(const double *c1, const doubl
                                                    fl_f_fd_cb f_fd, double *x, double *a, const double *p, double *fx,
                                                    const double *phid0, double *fdx, const int *dim,
                                                    const double *Increment);
+
+/* subroutine LagrangianMultiplier(fd,fdd,c,cd,cdd,x,lambda,N,M,Warning,MaxIteration,Precision)  NO.f90:1950-1993
+ * (Fortran only in the reference).  Warning / MaxIteration / Precision may be NULL (true / 1000 / 1e-15). */
+void __nonlinearoptimization_MOD_lagrangianmultiplier(fl_fd_cb fd, fl_fdd_cb fdd, fl_c_cb c, fl_cd_cb cd, fl_cdd_cb cdd,
+                                                      double *x, double *lambda, const int *N, const int *M,
+                                                      const int32_t *Warning, const int *MaxIteration,
+                                                      const double *Precision);
+void nonlinearoptimization_mp_lagrangianmultiplier_(fl_fd_cb fd, fl_fdd_cb fdd, fl_c_cb c, fl_cd_cb cd, fl_cdd_cb cdd,
+                                                    double *x, double *lambda, const int *N, const int *M,
+                                                    const int32_t *Warning, const int *MaxIteration,
+                                                    const double *Precision);
 
 /* Import-time symbols of the reference's Python package (FortranLibrary/General.py:4-16 probes
  * general_mp_showtime_ / __general_MOD_showtime when the package is imported, so `CDLL('libFL.so')` users keep

@@ -160,6 +160,11 @@ int fl_newton_raphson_batched(int objective, int batch, int n, double *x_dev, co
  * them: b untouched, A partially factorised). */
 int fl_dposv_batched(int batch, int n, double *A_dev, double *b_dev, int32_t *info_dev, void *stream);
 int fl_dpotri_batched(int batch, int n, double *A_dev, double *work_dev, int32_t *info_dev, void *stream);
+/*   fl_dsysv_batched  <- My_dsysv  LinearAlgebra.f90:695-703 (LAPACK dsysv 'L'): symmetric INDEFINITE systems given by
+ *                        their lower triangle (the KKT systems of LagrangianMultiplier, NO.f90:1984); A is destroyed,
+ *                        b [batch][n] <- A^{-1} b; info: 0, or k+1 if no non-zero pivot exists at step k (b untouched).
+ *                        Elimination with partial pivoting; n <= 4096. */
+int fl_dsysv_batched(int batch, int n, double *A_dev, double *b_dev, int32_t *info_dev, void *stream);
 
 /* The BFGS inverse-Hessian update AS THE REFERENCE WRITES IT: U = I - rho y s^T, rho = 1/(y.s),
  * H <- matmul(transpose(U), matmul(H, U)) + rho s s^T  (NO.f90:958-962; LinearAlgebra.f90:105-114

@@ -696,6 +696,108 @@ int flo_dpotri_lower(double *A, int n)
  * fails.  Forward substitution column-oriented (dtrsv 'L','N'); backward x_j = (z_j - sum_{i>j} L(i,j) x_i)
  * / L(j,j) with the sum taken top-down in FLO_SUM_SEQ (reference BLAS order is bottom-up: same value to
  * rounding) and in the kernels' reduction order in FLO_SUM_TREE. */
+/* My_dsysv (LA.f90:695-703: dsysv 'L', symmetric indefinite): the kernels' restatement -- the matrix the lower
+ * triangle defines, Gaussian elimination with partial pivoting (largest |a|, ties to the smaller row index), rows
+ * never moved, right-hand side carried along, back substitution in axpy form (csrc/fl_dense_kernels.hip
+ * dsysv_kernel).  LAPACK's Bunch-Kaufman factorisation inside MKL gives the same solution to rounding.
+ * Returns info (0, or k+1 when no non-zero pivot is left at step k; b untouched then). */
+int flo_dsysv(double *A, double *b, int n)
+{
+    size_t N = (size_t)n;
+    int *pstep = (int *)malloc(sizeof(int) * 2 * N), *piv = pstep + N;
+    double *w = (double *)malloc(sizeof(double) * N);
+    int info = 0;
+    for (int j = 1; j < n; ++j)
+        for (int i = 0; i < j; ++i) A[j * N + i] = A[i * N + j];
+    memcpy(w, b, sizeof(double) * N);
+    for (int i = 0; i < n; ++i) pstep[i] = n;
+    for (int k = 0; k < n && info == 0; ++k) {
+        double best = -1.0;
+        int p = -1;
+        for (int i = 0; i < n; ++i)
+            if (pstep[i] == n && fabs(A[k * N + i]) > best) {
+                best = fabs(A[k * N + i]);
+                p = i;
+            }
+        if (!(best > 0.0)) {
+            info = k + 1;
+            break;
+        }
+        piv[k] = p;
+        pstep[p] = k;
+        const double apk = A[k * N + p], bp = w[p];
+        for (int i = 0; i < n; ++i) {
+            if (pstep[i] != n) continue;
+            const double l = A[k * N + i] / apk;
+            w[i] = w[i] - l * bp;
+            if (l != 0.0)
+                for (int j = k + 1; j < n; ++j) A[j * N + i] = A[j * N + i] - l * A[j * N + p];
+        }
+    }
+    if (info == 0) {
+        for (int k = n - 1; k >= 0; --k) {
+            const int p = piv[k];
+            const double xk = w[p] / A[k * N + p];
+            for (int i = 0; i < n; ++i)
+                if (pstep[i] < k) w[i] = w[i] - A[k * N + i] * xk;
+            b[k] = xk;
+        }
+    }
+    free(w);
+    free(pstep);
+    return info;
+}
+
+/* LagrangianMultiplier, NO.f90:1950-1993: Newton iteration on the KKT system of L = f - lambda.c.
+ * -L' = [C lambda - f'; c],  L'' = [f'' - sum_k lambda_k c''_k, .; -C^T, 0] (lower triangle), solved by My_dsysv.
+ * The assembly and the convergence test are plain sequential sums (they run next to the callbacks on the host in
+ * the MI355X build), the solve is flo_dsysv.  Returns the number of Newton steps taken. */
+int flo_lagrangian_multiplier(flo_fd_t fd, flo_fdd_t fdd, flo_c_t c, flo_cd_t cd, flo_cdd_t cdd, double *x,
+                              double *lambda, int n, int m, int maxit, double precision, void *ctx)
+{
+    const int dim = n + m;
+    size_t N = (size_t)n, D = (size_t)dim;
+    const double tol = precision * precision;
+    double *mLd = (double *)malloc(sizeof(double) * (D + m + N * m + N * N * m + D * D));
+    double *cx = mLd + D, *cdx = cx + m, *cddx = cdx + N * m, *Ldd = cddx + N * N * m;
+    int it = 0;
+    for (int iter = 1; iter <= maxit; ++iter) {
+        fd(mLd, x, n, ctx);
+        c(cx, x, m, n, ctx);
+        cd(cdx, x, m, n, ctx);
+        for (int i = 0; i < n; ++i) { /* minusLd(1:N)=matmul(cdx,lambda)-minusLd(1:N) */
+            double t = 0.0;
+            for (int k = 0; k < m; ++k) t = t + cdx[k * N + i] * lambda[k];
+            mLd[i] = t - mLd[i];
+        }
+        for (int k = 0; k < m; ++k) mLd[n + k] = cx[k];
+        double nrm = 0.0;
+        for (int i = 0; i < dim; ++i) nrm = nrm + mLd[i] * mLd[i];
+        if (nrm < tol) break;
+        for (size_t q = 0; q < D * D; ++q) Ldd[q] = 0.0;
+        {
+            double *H = (double *)malloc(sizeof(double) * N * N);
+            fdd(H, x, n, ctx);
+            cdd(cddx, x, m, n, ctx);
+            for (int j = 0; j < n; ++j)
+                for (int i = 0; i < n; ++i) { /* Ldd(i,j)=fdd(i,j)-sum_k cddx(i,j,k) lambda_k */
+                    double t = 0.0;
+                    for (int k = 0; k < m; ++k) t = t + cddx[k * N * N + j * N + i] * lambda[k];
+                    Ldd[j * D + i] = H[j * N + i] - t;
+                }
+            free(H);
+        }
+        for (int k = 0; k < m; ++k)
+            for (int j = 0; j < n; ++j) Ldd[j * D + n + k] = -cdx[k * N + j]; /* Ldd(N+1:dim,1:N)=-transpose(cdx) */
+        if (flo_dsysv(Ldd, mLd, dim) != 0) break;
+        for (int i = 0; i < n; ++i) x[i] = x[i] + mLd[i];
+        for (int k = 0; k < m; ++k) lambda[k] = lambda[k] + mLd[n + k];
+        it = iter;
+    }
+    free(mLd);
+    return it;
+}
+
 int flo_dposv_lower(double *A, double *b, int n)
 {
 #define A_(i, j) A[(size_t)(j) * n + (i)]

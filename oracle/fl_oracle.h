@@ -97,6 +97,10 @@ void flo_bfgs(flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, flo_fdd_t fdd, double *x, 
 void flo_newton(flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, flo_fdd_t fdd, double *x, int n, const flo_opts *o, void *ctx,
                 flo_stats *st);
 int flo_dposv_lower(double *A, double *b, int n); /* My_dposv LA.f90:719 : returns info, b untouched if it fails */
+int flo_dsysv(double *A, double *b, int n);       /* My_dsysv LA.f90:695 : symmetric indefinite (lower), elimination with partial pivoting */
+typedef int (*flo_cdd_t)(double *cddx, const double *x, int m, int n, void *ctx); /* c''(x): N x N x M */
+int flo_lagrangian_multiplier(flo_fd_t fd, flo_fdd_t fdd, flo_c_t c, flo_cd_t cd, flo_cdd_t cdd, double *x,
+                              double *lambda, int n, int m, int maxit, double precision, void *ctx); /* NO.f90:1950 */
 /* AugmentedLagrangian (NO.f90:2005): solver 0 = BFGS, 1 = LBFGS, 2 = ConjugateGradient.
  * lambda[m] in/out (reference: lambda0 copy), miu0 as given. outer_iters returns the
  * number of outer iterations. */
@@ -125,6 +129,7 @@ int flo_prob_ffd(double *fx, double *g, const double *x, int n, void *ctx);
 int flo_prob_fdd(double *H, const double *x, int n, void *ctx);
 void flo_prob_c(double *cx, const double *x, int m, int n, void *ctx);
 void flo_prob_cd(double *cdx, const double *x, int m, int n, void *ctx);
+int flo_prob_cdd(double *cddx, const double *x, int m, int n, void *ctx);
 
 enum { FLO_SD = 0, FLO_CG = 1, FLO_LBFGS = 2, FLO_BFGS = 3 };
 /* batched driver, OpenMP over problems (one problem per thread, like the reference

@@ -138,6 +138,18 @@ void flo_prob_cd(double *cdx, const double *x, int m, int n, void *ctx)
         for (int i = j * w; i < (j + 1) * w; ++i) cdx[(size_t)j * n + i] = 2.0 * x[i];
 }
 
+/* c''_j = 2 I on block j: cddx(N,N,M) column-major */
+int flo_prob_cdd(double *cddx, const double *x, int m, int n, void *ctx)
+{
+    (void)ctx;
+    (void)x;
+    const int w = n / m;
+    memset(cddx, 0, sizeof(double) * (size_t)n * n * m);
+    for (int j = 0; j < m; ++j)
+        for (int i = j * w; i < (j + 1) * w; ++i) cddx[(size_t)j * n * n + (size_t)i * n + i] = 2.0;
+    return 0;
+}
+
 static void set_modes(int sum_mode, int threads, int ept) { flo_set_sum_mode(sum_mode, threads, ept); }
 
 int flo_solve_batch(int solver, int kind, int B, int n, double *x, const double *d, const double *b,

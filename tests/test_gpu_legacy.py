@@ -464,3 +464,92 @@ def test_legacy_augmented_lagrangian_dense_inner_solvers(solver, with_hessians, 
     g = 4.0 * x ** 3
     lam = (g @ x) / (2.0 * x @ x)  # f' = lambda c' at a constrained stationary point
     assert np.linalg.norm(g - lam * 2.0 * x) < 1e-5
+
+
+@pytest.mark.parametrize("n", [1, 2, 11, 64, 130, 300, 700])
+def test_dsysv_batched_bitexact_and_against_numpy(n):
+    """fl_dsysv_batched (My_dsysv, LA.f90:695-703): symmetric indefinite systems given by their lower triangle --
+    KKT-shaped ([H, C; C^T, 0]) and random ones; bit for bit the oracle's elimination, numpy's solution to rounding,
+    info > 0 and an untouched right-hand side for a singular matrix."""
+    import FortranLibrary.NonlinearOptimization as NLO
+    lib = O.lib()
+    dp = C.POINTER(C.c_double)
+    lib.flo_dsysv.argtypes = [dp, dp, C.c_int]
+    lib.flo_dsysv.restype = C.c_int
+    rng = np.random.default_rng(n)
+    T, E = NLO.reduction_geometry(n)
+    ld = T * E
+    B = 4
+    A = np.zeros((B, n, n))
+    for k in range(B):
+        if k % 2 == 0 and n >= 4:  # KKT shape: SPD block, constraint Jacobian, zero block
+            m = max(1, n // 5)
+            h = rng.standard_normal((n - m, n - m))
+            A[k, :n - m, :n - m] = h @ h.T / (n - m) + np.eye(n - m)
+            cj = rng.standard_normal((n - m, m))
+            A[k, :n - m, n - m:] = -cj
+            A[k, n - m:, :n - m] = -cj.T
+        else:
+            s = rng.standard_normal((n, n))
+            A[k] = s + s.T
+    if n >= 2:
+        A[3] = 0.0  # singular: first column has no non-zero entry
+        A[3, 1:, 1:] = np.eye(n - 1)
+    rhs = rng.standard_normal((B, n))
+    Ap = np.zeros((B, n, ld))
+    for k in range(B):
+        Ap[k, :, :n] = np.tril(A[k]).T  # column-major [col][row]: lower triangle only, upper left as garbage-free zeros
+    dev = torch.device("cuda:0")
+    Ad, bd = torch.tensor(Ap, device=dev), torch.tensor(rhs, device=dev)
+    info = NLO.dsysv(Ad, bd).cpu().numpy()
+    sol = bd.cpu().numpy()
+    for k in range(B):
+        a = np.ascontiguousarray(np.tril(A[k]).T)  # column-major n x n with the lower triangle
+        bb = rhs[k].copy()
+        oi = lib.flo_dsysv(a.ctypes.data_as(dp), bb.ctypes.data_as(dp), n)
+        assert info[k] == oi
+        assert np.array_equal(sol[k], bb)
+        if oi == 0:
+            assert np.allclose(sol[k], np.linalg.solve(A[k], rhs[k]), rtol=1e-7, atol=1e-9)
+        else:
+            assert np.array_equal(sol[k], rhs[k])
+    if n >= 2:
+        assert info[3] == 1
+
+
+def test_legacy_lagrangian_multiplier_unit_sphere():
+    """LagrangianMultiplier (NO.f90:1950-1993) through its mangled symbol: quartic, dim 10, constraint x.x = 1, from a
+    start near the constrained minimiser (the method is a Newton iteration on the KKT system: local).  Callbacks on
+    the host, the symmetric indefinite solve on the GPU; equal to the oracle bit for bit; |x| = 1, f' = lambda c'."""
+    FL = _fl()
+    n, m = 10, 1
+    f, fd, ffd, cnt, (T, E), P = _callbacks(O.QUARTIC, n)
+    lib = O.lib()
+    dp = C.POINTER(C.c_double)
+    for name in ("flo_prob_c", "flo_prob_cd", "flo_prob_cdd"):
+        getattr(lib, name).argtypes = [dp, dp, C.c_int, C.c_int, C.c_void_p]
+    lib.flo_prob_fdd.argtypes = [dp, dp, C.c_int, C.c_void_p]
+    CDD_CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int))
+    c = C_CB(lambda cx, x, M, N: lib.flo_prob_c(cx, x, M[0], N[0], None))
+    cd = C_CB(lambda cdx, x, M, N: lib.flo_prob_cd(cdx, x, M[0], N[0], None))
+    cdd = CDD_CB(lambda cddx, x, M, N: lib.flo_prob_cdd(cddx, x, M[0], N[0], None))
+    fdd = FDD_CB(lambda H, x, dim: lib.flo_prob_fdd(H, x, dim[0], C.byref(P)))
+    rng = np.random.default_rng(1)
+    x0 = np.full(n, 1.0 / np.sqrt(n)) * (1.0 + 0.05 * rng.uniform(-1, 1, n))
+    lam0 = np.array([0.2])
+    x, lam = x0.copy(), lam0.copy()
+    N_, M_ = C.c_int(n), C.c_int(m)
+    FL.__nonlinearoptimization_MOD_lagrangianmultiplier(fd, fdd, c, cd, cdd, x.ctypes.data_as(dp), lam.ctypes.data_as(dp),
+                                                        C.byref(N_), C.byref(M_), C.byref(C.c_int32(0)), C.byref(C.c_int(50)),
+                                                        C.byref(C.c_double(1e-12)))
+    assert abs(np.linalg.norm(x) - 1.0) < 1e-10
+    assert np.linalg.norm(4.0 * x ** 3 - lam[0] * 2.0 * x) < 1e-10
+    lib.flo_lagrangian_multiplier.argtypes = [C.c_void_p] * 5 + [dp, dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]
+    lib.flo_lagrangian_multiplier.restype = C.c_int
+    xo, lo = x0.copy(), lam0.copy()
+    addr = lambda fn: C.cast(fn, C.c_void_p)
+    its = lib.flo_lagrangian_multiplier(addr(lib.flo_prob_fd), addr(lib.flo_prob_fdd), addr(lib.flo_prob_c), addr(lib.flo_prob_cd),
+                                        addr(lib.flo_prob_cdd), xo.ctypes.data_as(dp), lo.ctypes.data_as(dp), n, m, 50, 1e-12,
+                                        C.cast(C.byref(P), C.c_void_p))
+    assert 1 <= its < 50
+    assert np.array_equal(x, xo) and np.array_equal(lam, lo)
