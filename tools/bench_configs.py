@@ -5,7 +5,7 @@ Not the driver's bench (that is bench.py = the north-star headline); this record
 for the remaining rows of SURVEY.md section 8.  Same method: inputs generated on the device, one launch of the
 fused kernel per solve, HIP events on the launch stream, algorithmic bytes per SURVEY.md 8(d), CPU oracle
 (reference summation order, OpenMP one problem per thread on the cgroup's cores) on a bounded sample.
-usage: python tools/bench_configs.py [c1 c2 c3 c4 c4gemm c5 newton dense] [--cpu-seconds 10]
+usage: python tools/bench_configs.py [c1 c2 c3 c4 c4gemm c5 newton dense big] [--cpu-seconds 10]
 """
 import argparse
 import json
@@ -266,6 +266,38 @@ def main():
                               "dposv_max_residual": res, "dpotri_ms": ms2 - ms_copy,
                               "dpotri_GFLOPs": B * (n ** 3) / (ms2 - ms_copy) / 1e6, "dpotri_max_abs_AinvA_minus_I": err,
                               "all_info_zero": bool((info == 0).all() and (info2 == 0).all())}))
+
+    if "big" in args.configs:  # beyond the register path (n > 4096): vectors in HBM, one workgroup per problem
+        for B, n in ((4096, 8192), (1024, 65536)):
+            m = 10
+            d, b = quad(B, n, 10.0, 1000.0)
+            x = torch.zeros(B, n, dtype=torch.float64, device=dev)
+            ws = NLO.workspace(B, n, m, dev)
+
+            def run():
+                x.zero_()
+                return NLO.LBFGS(NLO.DIAGQUAD, x, d, b, workspace_=ws, Precision=1e-6, MaxIteration=3000, Memory=m)
+            out, ms = timed(run, 2)
+            it = out["iters"].to(torch.int64)
+            nfg = out["nf"].to(torch.int64) + out["ng"].to(torch.int64)
+            k = torch.clamp(it - 1, min=0)
+            part = torch.clamp(k, max=m)
+            cnt = part * (part + 1) // 2 + torch.clamp(k - m, min=0) * m
+            algo = float((8 * n * (4 * cnt + 2 * k)).sum())            # SURVEY 8d two-loop bytes
+            moved = float((8 * n * (6 * cnt + 10 * k + 3 * nfg)).sum())  # what the pass-wise form streams (fl_big.hpp)
+            Bc = min(B, cores)
+            oo = O.defaults(precision=1e-6, maxit=3000, memory=m)
+            t = time.perf_counter()
+            ref = O.solve_batch(O.LBFGS, O.DIAGQUAD, np.zeros((Bc, n)), d=d[:Bc].cpu().numpy(), b=b[:Bc].cpu().numpy(), opts=oo,
+                                nthreads=cores)
+            dt = time.perf_counter() - t
+            print(json.dumps({"config": f"L-BFGS m=10 beyond the register path: diagonal quadratics n={n}, batch {B}, Precision 1e-6",
+                              "ms": ms, "iterations_per_s": float(it.sum()) / ms * 1e3, "iterations": int(it.sum()),
+                              "converged_fraction": float((out["status"] == 0).double().mean()),
+                              "algorithmic_GBps_two_loop": algo / ms / 1e6, "moved_GBps_model": moved / ms / 1e6,
+                              "cpu_iterations_per_s": float(ref["iters"].sum()) / dt, "cpu": host, "cpu_sample": Bc,
+                              "final_f_rel_err_max_vs_cpu": float(np.max(np.abs(out["f"][:Bc].cpu().numpy() - ref["f"])
+                                                                         / np.abs(ref["f"])))}))
 
     if "c5" in args.configs:  # aug-Lagrangian wrapping L-BFGS, batch 8192 n=512, 8 equality constraints
         B, n, M, m = 8192, 512, 8, 10
