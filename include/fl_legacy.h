@@ -131,6 +131,16 @@ void nonlinearoptimization_mp_lagrangianmultiplier_(fl_fd_cb fd, fl_fdd_cb fdd, 
                                                     const int32_t *Warning, const int *MaxIteration,
                                                     const double *Precision);
 
+/* LinearAlgebra entry points the reference's C++ header binds (cpp/FortranLibrary.hpp:48-63; LinearAlgebra.f90:182-196,
+ * 879-887).  Host arrays, column-major; handed to rocBLAS dgemm / rocSOLVER dsyev on the GPU (the reference hands
+ * them to MKL): same results to rounding, eigenvectors up to sign. */
+void __linearalgebra_MOD_my_dgemm(const double *A, const double *B, double *C, const int *M, const int *K, const int *N);
+void __linearalgebra_MOD_my_dgemm_t(const double *A, const double *B, double *C, const int *M, const int *K, const int *N);
+void __linearalgebra_MOD_my_dsyev(const char *jobtype, double *A, double *eigval, const int *N, int len_jobtype);
+void linearalgebra_mp_my_dgemm_(const double *A, const double *B, double *C, const int *M, const int *K, const int *N);
+void linearalgebra_mp_my_dgemm_t_(const double *A, const double *B, double *C, const int *M, const int *K, const int *N);
+void linearalgebra_mp_my_dsyev_(const char *jobtype, double *A, double *eigval, const int *N, int len_jobtype);
+
 /* Import-time symbols of the reference's Python package (FortranLibrary/General.py:4-16 probes
  * general_mp_showtime_ / __general_MOD_showtime when the package is imported, so `CDLL('libFL.so')` users keep
  * importing it against this library).  Host utilities, restated from source/General.f90:29-55:

@@ -553,3 +553,32 @@ def test_legacy_lagrangian_multiplier_unit_sphere():
                                         C.cast(C.byref(P), C.c_void_p))
     assert 1 <= its < 50
     assert np.array_equal(x, xo) and np.array_equal(lam, lo)
+
+
+def test_linear_algebra_symbols_of_the_cpp_header():
+    """__linearalgebra_MOD_my_dgemm(_t) and __linearalgebra_MOD_my_dsyev (cpp/FortranLibrary.hpp:48-63): host arrays
+    in and out like the reference, rocBLAS / rocSOLVER underneath; numpy to rounding."""
+    FL = _fl()
+    rng = np.random.default_rng(0)
+    dp = C.POINTER(C.c_double)
+    M, K, N = 37, 53, 29
+    A = np.asfortranarray(rng.standard_normal((M, K)))
+    At = np.asfortranarray(A.T.copy())  # K x M
+    B = np.asfortranarray(rng.standard_normal((K, N)))
+    Cm = np.asfortranarray(np.zeros((M, N)))
+    iM, iK, iN = C.c_int(M), C.c_int(K), C.c_int(N)
+    FL.__linearalgebra_MOD_my_dgemm(A.ctypes.data_as(dp), B.ctypes.data_as(dp), Cm.ctypes.data_as(dp), C.byref(iM), C.byref(iK), C.byref(iN))
+    assert np.allclose(Cm, A @ B, rtol=1e-13, atol=1e-13)
+    Cm[:] = 0.0
+    FL.__linearalgebra_MOD_my_dgemm_t(At.ctypes.data_as(dp), B.ctypes.data_as(dp), Cm.ctypes.data_as(dp), C.byref(iM), C.byref(iK), C.byref(iN))
+    assert np.allclose(Cm, A @ B, rtol=1e-13, atol=1e-13)
+    n = 41
+    S = rng.standard_normal((n, n))
+    S = np.asfortranarray(S + S.T)
+    S0 = S.copy()
+    w = np.zeros(n)
+    i_n = C.c_int(n)
+    FL.__linearalgebra_MOD_my_dsyev(b"V", S.ctypes.data_as(dp), w.ctypes.data_as(dp), C.byref(i_n), C.c_int(1))
+    assert np.allclose(w, np.linalg.eigvalsh(S0), rtol=1e-12, atol=1e-12) and np.all(np.diff(w) >= 0)
+    assert np.allclose(S0 @ S, S * w[None, :], rtol=1e-10, atol=1e-10)      # A v_k = w_k v_k
+    assert np.allclose(S.T @ S, np.eye(n), atol=1e-12)                       # normalised eigenvectors
