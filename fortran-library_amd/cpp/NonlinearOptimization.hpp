@@ -96,6 +96,19 @@ inline void NewtonRaphson(f_t f, fd_t fd, f_fd_t f_fd, fdd_t fdd, double *x, con
                                               detail::as<fl_fdd_cb>(fdd), detail::as<fl_f_fd_cb>(f_fd), FL_NO_PASS(k));
 }
 
+// hpp:494-511: residue(f'(x), x, M, N), Jacobian(J(x), x, M, N); an own Levenberg-Marquardt iteration stands in for
+// MKL's trnlsp (include/fl_legacy.h)
+inline void TrustRegion(void (*residue)(double *, const double *, const int &, const int &),
+                        void (*Jacobian)(double *, const double *, const int &, const int &), double *x, const int &M,
+                        const int &N, const bool &Warning = true, const int &MaxIteration = 1000,
+                        const int &MaxStepIteration = 100, const double &Precision = 1e-15,
+                        const double &MinStepLength = 1e-15)
+{
+    const int32_t w = Warning ? -1 : 0;
+    __nonlinearoptimization_MOD_trustregion_basic(detail::as<fl_residue_cb>(residue), detail::as<fl_jacobian_cb>(Jacobian), x,
+                                                  &M, &N, &w, &MaxIteration, &MaxStepIteration, &Precision, &MinStepLength);
+}
+
 // lambda0 empty = zeros (hpp:575-578)
 inline void AugmentedLagrangian(f_t f, fd_t fd, f_fd_t f_fd, fdd_t fdd, c_t c, cd_t cd, cdd_t cdd, double *x,
                                 const int &N, const int &M, const std::string &UnconstrainedSolver = "BFGS",

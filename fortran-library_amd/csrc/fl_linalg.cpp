@@ -9,8 +9,13 @@
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 
+#include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <mutex>
+#include <vector>
+
+#include "../../include/fl_nlopt.h"
 
 namespace {
 
@@ -113,6 +118,172 @@ void linearalgebra_mp_my_dgemm_t_(const double *A, const double *B, double *C, c
 void linearalgebra_mp_my_dsyev_(const char *jobtype, double *A, double *eigval, const int *N, int len)
 {
     __linearalgebra_MOD_my_dsyev(jobtype, A, eigval, N, len);
+}
+
+} // extern "C"
+
+// ------------------------------------------------------------------ TrustRegion
+// subroutine TrustRegion(fd,x,M,N,Jacobian,low,up,Warning,MaxIteration,MaxStepIteration,Precision,MinStepLength)
+// and TrustRegion_basic (NO.f90:1728-1906, 2348-2423; hpp:358-366): solve f'(x) = 0 by minimising |f'(x)|^2.
+// The reference is a wrapper of MKL's closed RCI solver dtrnlsp -- there is no algorithm in the reference to restate
+// (SURVEY.md 8f.4), so this is an own Levenberg-Marquardt iteration with Nielsen's damping update behind the same
+// interface and stopping options: PARITY UNPINNED by construction (same stationary points, different path).
+// Callbacks on the host; J^T J, J^T f' through rocBLAS and the damped normal equations through fl_dposv_batched on
+// the GPU.  Bounds (low, up) are honoured by projecting every trial point.
+typedef void (*res_cb)(double *, const double *, const int &, const int &);
+typedef int (*jac_cb)(double *, const double *, const int &, const int &);
+
+static void trust_region(res_cb fd, jac_cb Jacobian, double *x, int M, int N, const double *low, const double *up, int warn,
+                         int maxit, int maxstepit, double precision, double minstep)
+{
+    int threads = 0, ept = 0;
+    if (N <= 0 || M < N || N > 4096 || fl_reduction_geometry(N, &threads, &ept) != FL_OK) {
+        std::fprintf(stderr, "FortranLibrary(MI355X) TrustRegion: needs 0 < N <= M, N <= 4096; x is unchanged\n");
+        return;
+    }
+    const size_t ld = (size_t)threads * ept;
+    std::vector<double> r(M), rn(M), J((size_t)M * N), A((size_t)N * N), g(N), d(N), xn(N), Ap((size_t)N * ld), rp(M), rm(M);
+    double *Ad = nullptr, *bd = nullptr;
+    int32_t *infod = nullptr;
+    bool ok = hipMalloc((void **)&Ad, sizeof(double) * N * ld) == hipSuccess &&
+              hipMalloc((void **)&bd, sizeof(double) * N) == hipSuccess &&
+              hipMalloc((void **)&infod, sizeof(int32_t)) == hipSuccess;
+    auto project = [&](double *v) {
+        if (low && up)
+            for (int i = 0; i < N; ++i) v[i] = v[i] < low[i] ? low[i] : (v[i] > up[i] ? up[i] : v[i]);
+    };
+    auto sq = [](const std::vector<double> &v) {
+        double t = 0.0;
+        for (double e : v) t += e * e;
+        return t;
+    };
+    auto jacobian = [&](const double *xx) { // analytical, or central differences of f' (the reference: MKL djacobi)
+        if (Jacobian) {
+            (void)Jacobian(J.data(), xx, M, N);
+            return;
+        }
+        std::vector<double> xp(xx, xx + N);
+        for (int j = 0; j < N; ++j) {
+            const double h = 1e-8 * std::fmax(1.0, std::fabs(xx[j]));
+            xp[j] = xx[j] + h;
+            fd(rp.data(), xp.data(), M, N);
+            xp[j] = xx[j] - h;
+            fd(rm.data(), xp.data(), M, N);
+            xp[j] = xx[j];
+            for (int i = 0; i < M; ++i) J[(size_t)j * M + i] = (rp[i] - rm[i]) / (2.0 * h);
+        }
+    };
+    auto normal_equations = [&]() { // A = J^T J, g = J^T r on the GPU
+        gemm(true, J.data(), J.data(), A.data(), N, M, N);
+        gemm(true, J.data(), r.data(), g.data(), N, M, 1);
+    };
+    project(x);
+    fd(r.data(), x, M, N);
+    double f2 = sq(r);
+    const double f2_0 = f2;
+    jacobian(x);
+    normal_equations();
+    double mu = 0.0;
+    for (int i = 0; i < N; ++i) mu = std::fmax(mu, A[(size_t)i * N + i]);
+    mu = (mu > 0.0 ? mu : 1.0) * 1e-3;
+    double nu = 2.0;
+    int it = 0, reason = 1;
+    bool stop = false;
+    for (it = 1; ok && !stop && it <= maxit; ++it) {
+        if (std::sqrt(f2) < precision) { reason = 3; break; } // || f'(x) ||_2 < Precision
+        bool accepted = false;
+        for (int step = 0; ok && step < maxstepit && !accepted; ++step) {
+            std::fill(Ap.begin(), Ap.end(), 0.0);
+            for (int j = 0; j < N; ++j)
+                for (int i = 0; i < N; ++i) Ap[(size_t)j * ld + i] = A[(size_t)j * N + i] + (i == j ? mu : 0.0);
+            for (int i = 0; i < N; ++i) d[i] = -g[i];
+            int32_t info = 0;
+            ok = hipMemcpy(Ad, Ap.data(), sizeof(double) * N * ld, hipMemcpyHostToDevice) == hipSuccess &&
+                 hipMemcpy(bd, d.data(), sizeof(double) * N, hipMemcpyHostToDevice) == hipSuccess &&
+                 fl_dposv_batched(1, N, Ad, bd, infod, nullptr) == FL_OK &&
+                 hipMemcpy(&info, infod, sizeof info, hipMemcpyDeviceToHost) == hipSuccess &&
+                 hipMemcpy(d.data(), bd, sizeof(double) * N, hipMemcpyDeviceToHost) == hipSuccess;
+            if (!ok) break;
+            if (info == 0) {
+                for (int i = 0; i < N; ++i) xn[i] = x[i] + d[i];
+                project(xn.data());
+                double s2 = 0.0, pred = 0.0;
+                for (int i = 0; i < N; ++i) {
+                    const double di = xn[i] - x[i];
+                    s2 += di * di;
+                    pred += di * (mu * di - g[i]);
+                }
+                if (std::sqrt(s2) < minstep) { reason = 5; stop = true; break; } // || s ||_2 < MinStepLength
+                fd(rn.data(), xn.data(), M, N);
+                const double f2n = sq(rn), rho = (f2 - f2n) / (pred > 0.0 ? pred : 1e-300);
+                if (f2n < f2 && rho > 0.0) {
+                    for (int i = 0; i < N; ++i) x[i] = xn[i];
+                    r.swap(rn);
+                    f2 = f2n;
+                    const double t = 2.0 * rho - 1.0;
+                    mu = mu * std::fmax(1.0 / 3.0, 1.0 - t * t * t);
+                    nu = 2.0;
+                    accepted = true;
+                    continue;
+                }
+            }
+            mu = mu * nu; // rejected (or not positive definite): shrink the trust region
+            nu = 2.0 * nu;
+        }
+        if (stop) break;
+        if (!accepted) { reason = 2; break; } // no acceptable step within MaxStepIteration: radius exhausted
+        jacobian(x);
+        normal_equations();
+        double gmax = 0.0;
+        for (int i = 0; i < N; ++i) gmax = std::fmax(gmax, std::fabs(g[i]));
+        if (gmax == 0.0) { reason = 4; break; } // stationary point of the merit function
+    }
+    if (!ok) std::fprintf(stderr, "FortranLibrary(MI355X) TrustRegion: HIP error\n");
+    if (ok && warn && reason != 3) { // the reference's report (NO.f90:1880-1904), reasons renumbered for this solver
+        if (reason == 1) std::printf(" Failed trust region: max iteration exceeded!\n");
+        else std::printf(" Trust region warning: stopped before || f'(x) ||_2 met the precision (reason %d)\n", reason);
+        std::printf(" Final residual = %24.16E   (initial %24.16E)\n", std::sqrt(f2), std::sqrt(f2_0));
+    }
+    if (Ad) (void)hipFree(Ad);
+    if (bd) (void)hipFree(bd);
+    if (infod) (void)hipFree(infod);
+}
+
+extern "C" {
+
+void __nonlinearoptimization_MOD_trustregion_basic(res_cb fd, jac_cb Jacobian, double *x, const int *M, const int *N,
+                                                   const int32_t *Warning, const int *MaxIteration,
+                                                   const int *MaxStepIteration, const double *Precision,
+                                                   const double *MinStepLength)
+{
+    trust_region(fd, Jacobian, x, *M, *N, nullptr, nullptr, *Warning != 0, *MaxIteration, *MaxStepIteration, *Precision,
+                 *MinStepLength);
+}
+void nonlinearoptimization_mp_trustregion_basic_(res_cb fd, jac_cb Jacobian, double *x, const int *M, const int *N,
+                                                 const int32_t *Warning, const int *MaxIteration,
+                                                 const int *MaxStepIteration, const double *Precision,
+                                                 const double *MinStepLength)
+{
+    __nonlinearoptimization_MOD_trustregion_basic(fd, Jacobian, x, M, N, Warning, MaxIteration, MaxStepIteration, Precision,
+                                                  MinStepLength);
+}
+// the general routine: every argument after N is optional (NULL = absent)
+void __nonlinearoptimization_MOD_trustregion(res_cb fd, double *x, const int *M, const int *N, jac_cb Jacobian,
+                                             const double *low, const double *up, const int32_t *Warning,
+                                             const int *MaxIteration, const int *MaxStepIteration, const double *Precision,
+                                             const double *MinStepLength)
+{
+    trust_region(fd, Jacobian, x, *M, *N, (low && up) ? low : nullptr, (low && up) ? up : nullptr,
+                 Warning ? *Warning != 0 : 1, MaxIteration ? *MaxIteration : 1000, MaxStepIteration ? *MaxStepIteration : 100,
+                 Precision ? *Precision : 1e-15, MinStepLength ? *MinStepLength : 1e-15);
+}
+void nonlinearoptimization_mp_trustregion_(res_cb fd, double *x, const int *M, const int *N, jac_cb Jacobian,
+                                           const double *low, const double *up, const int32_t *Warning,
+                                           const int *MaxIteration, const int *MaxStepIteration, const double *Precision,
+                                           const double *MinStepLength)
+{
+    __nonlinearoptimization_MOD_trustregion(fd, x, M, N, Jacobian, low, up, Warning, MaxIteration, MaxStepIteration, Precision,
+                                            MinStepLength);
 }
 
 } // extern "C"

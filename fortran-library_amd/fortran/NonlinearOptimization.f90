@@ -20,7 +20,8 @@
 !  AugmentedLagrangian <- reference NonlinearOptimization.f90:2005 (inner solvers LBFGS / ConjugateGradient / BFGS / NewtonRaphson)
 !  Wolfe, Wolfe_fdwithf, StrongWolfe, StrongWolfe_fdwithf <- reference NonlinearOptimization.f90:1286, 1373, 1462, 1582
 !  LagrangianMultiplier <- reference NonlinearOptimization.f90:1950
-!Not provided (SURVEY.md sections 2, 8f): TrustRegion (MKL RCI).
+!  TrustRegion, TrustRegion_basic <- reference NonlinearOptimization.f90:1728, 2348 (own Levenberg-Marquardt
+!      iteration behind the interface of the MKL trnlsp wrapper)
 module NonlinearOptimization
     use iso_c_binding
     implicit none
@@ -118,6 +119,14 @@ module NonlinearOptimization
             integer(c_int),intent(in)::N,M
             type(c_ptr),value::Warning,MaxIteration,Precision
         end subroutine flc_lagrangianmultiplier
+        subroutine flc_trustregion(fd,x,M,N,Jacobian,low,up,Warning,MaxIteration,MaxStepIteration,Precision,MinStepLength)&
+        bind(C,name='__nonlinearoptimization_MOD_trustregion')
+            import
+            type(c_funptr),value::fd,Jacobian
+            real(c_double)::x(*)
+            integer(c_int),intent(in)::M,N
+            type(c_ptr),value::low,up,Warning,MaxIteration,MaxStepIteration,Precision,MinStepLength
+        end subroutine flc_trustregion
         subroutine fl_default_options(opt,solver) bind(C,name='fl_default_options')
             import
             type(fl_options),intent(out)::opt
@@ -330,6 +339,48 @@ contains
         pfdd=c_null_funptr; if(present(fdd)) pfdd=c_funloc(fdd)
         call flc_newtonraphson(c_funloc(f),c_funloc(fd),x,dim,pfdd,pf_fd,p(1),p(2),p(3),p(4),p(5),p(6),p(7),p(8))
     end subroutine NewtonRaphson
+
+    !Trust region (reference NonlinearOptimization.f90:1728-1906, 2348-2423): solve f'(x) = 0 by minimising |f'(x)|^2.
+    !The reference wraps MKL's closed trnlsp solver; behind the same interface this build runs an own
+    !Levenberg-Marquardt iteration (callbacks on the host, normal equations on the device): same stationary points
+    !    subroutine fd(f'(x), x, M, N);  integer function Jacobian(J(x), x, M, N), M x N; M >= N
+    subroutine TrustRegion(fd, x, M, N, &
+    Jacobian, low, up, Warning, MaxIteration, MaxStepIteration, Precision, MinStepLength)
+        external::fd
+        integer,intent(in)::M,N
+        real*8,dimension(N),intent(inout)::x
+        integer,external,optional::Jacobian
+        real*8,dimension(N),intent(in),optional,target::low,up
+        logical,intent(in),optional::Warning
+        integer,intent(in),optional::MaxIteration,MaxStepIteration
+        real*8 ,intent(in),optional::Precision,MinStepLength
+        integer(c_int32_t),target::lw
+        integer(c_int),target::lmax,lstep
+        real(c_double),target::lp,lmin
+        type(c_ptr)::pl,pu,pw,pm,ps,pp,pn
+        type(c_funptr)::pj
+        pj=c_null_funptr; if(present(Jacobian)) pj=c_funloc(Jacobian)
+        pl=c_null_ptr; pu=c_null_ptr
+        if(present(low).and.present(up)) then; pl=c_loc(low); pu=c_loc(up); end if
+        pw=c_null_ptr; if(present(Warning)) then; lw=merge(1,0,Warning); pw=c_loc(lw); end if
+        pm=c_null_ptr; if(present(MaxIteration)) then; lmax=MaxIteration; pm=c_loc(lmax); end if
+        ps=c_null_ptr; if(present(MaxStepIteration)) then; lstep=MaxStepIteration; ps=c_loc(lstep); end if
+        pp=c_null_ptr; if(present(Precision)) then; lp=Precision; pp=c_loc(lp); end if
+        pn=c_null_ptr; if(present(MinStepLength)) then; lmin=MinStepLength; pn=c_loc(lmin); end if
+        call flc_trustregion(c_funloc(fd),x,M,N,pj,pl,pu,pw,pm,ps,pp,pn)
+    end subroutine TrustRegion
+    subroutine TrustRegion_basic(fd, Jacobian, x, M, N, &
+    Warning, MaxIteration, MaxStepIteration, Precision, MinStepLength)
+        external::fd
+        integer,external::Jacobian
+        integer,intent(in)::M,N
+        real*8,dimension(N),intent(inout)::x
+        logical,intent(in)::Warning
+        integer,intent(in)::MaxIteration,MaxStepIteration
+        real*8 ,intent(in)::Precision,MinStepLength
+        call TrustRegion(fd,x,M,N,Jacobian=Jacobian,Warning=Warning,MaxIteration=MaxIteration,&
+            MaxStepIteration=MaxStepIteration,Precision=Precision,MinStepLength=MinStepLength)
+    end subroutine TrustRegion_basic
 
     !Lagrangian multiplier method (reference NonlinearOptimization.f90:1950-1993): Newton iteration on the KKT system;
     !on input lambda is an initial guess of the multipliers, on exit the solution.  fd, fdd, c, cd, cdd are evaluated on

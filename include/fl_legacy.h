@@ -27,7 +27,6 @@
  * (Cholesky solve / inverse there); without fdd the reference calls MKL djacobi (closed, step rule unpublished):
  * here central differences of the caller's fd, h = 1e-8 max(1,|x_j|), 2n gradient calls per Hessian -- same
  * end points, not bit-identical ("parity unpinned" for this branch).
- * TrustRegion (MKL RCI) is not exported (out of scope).
  */
 #ifndef FL_LEGACY_H
 #define FL_LEGACY_H
@@ -130,6 +129,30 @@ void nonlinearoptimization_mp_lagrangianmultiplier_(fl_fd_cb fd, fl_fdd_cb fdd, 
                                                     double *x, double *lambda, const int *N, const int *M,
                                                     const int32_t *Warning, const int *MaxIteration,
                                                     const double *Precision);
+
+/* TrustRegion / TrustRegion_basic (NO.f90:1728-1906, 2348-2423; hpp:358-366): f'(x) = 0 by minimising |f'(x)|^2.
+ * The reference wraps MKL's closed dtrnlsp solver; here an own Levenberg-Marquardt iteration sits behind the same
+ * interface (callbacks on the host, J^T J / damped normal equations on the GPU): same stationary points, parity
+ * unpinned by construction.  subroutine fd(f'(x),x,M,N); integer function Jacobian(J(x),x,M,N), J is M x N. */
+typedef void (*fl_residue_cb)(double *fdx, const double *x, const int *M, const int *N);
+typedef int (*fl_jacobian_cb)(double *Jx, const double *x, const int *M, const int *N);
+void __nonlinearoptimization_MOD_trustregion_basic(fl_residue_cb fd, fl_jacobian_cb Jacobian, double *x, const int *M,
+                                                   const int *N, const int32_t *Warning, const int *MaxIteration,
+                                                   const int *MaxStepIteration, const double *Precision,
+                                                   const double *MinStepLength);
+void nonlinearoptimization_mp_trustregion_basic_(fl_residue_cb fd, fl_jacobian_cb Jacobian, double *x, const int *M,
+                                                 const int *N, const int32_t *Warning, const int *MaxIteration,
+                                                 const int *MaxStepIteration, const double *Precision,
+                                                 const double *MinStepLength);
+/* Fortran's general routine: Jacobian, low, up and everything after them may be NULL (absent) */
+void __nonlinearoptimization_MOD_trustregion(fl_residue_cb fd, double *x, const int *M, const int *N,
+                                             fl_jacobian_cb Jacobian, const double *low, const double *up,
+                                             const int32_t *Warning, const int *MaxIteration, const int *MaxStepIteration,
+                                             const double *Precision, const double *MinStepLength);
+void nonlinearoptimization_mp_trustregion_(fl_residue_cb fd, double *x, const int *M, const int *N,
+                                           fl_jacobian_cb Jacobian, const double *low, const double *up,
+                                           const int32_t *Warning, const int *MaxIteration, const int *MaxStepIteration,
+                                           const double *Precision, const double *MinStepLength);
 
 /* LinearAlgebra entry points the reference's C++ header binds (cpp/FortranLibrary.hpp:48-63; LinearAlgebra.f90:182-196,
  * 879-887).  Host arrays, column-major; handed to rocBLAS dgemm / rocSOLVER dsyev on the GPU (the reference hands

@@ -582,3 +582,59 @@ def test_linear_algebra_symbols_of_the_cpp_header():
     assert np.allclose(w, np.linalg.eigvalsh(S0), rtol=1e-12, atol=1e-12) and np.all(np.diff(w) >= 0)
     assert np.allclose(S0 @ S, S * w[None, :], rtol=1e-10, atol=1e-10)      # A v_k = w_k v_k
     assert np.allclose(S.T @ S, np.eye(n), atol=1e-12)                       # normalised eigenvectors
+
+
+RES_CB = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int))
+JAC_CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int))
+
+
+@pytest.mark.parametrize("analytic", [True, False])
+def test_trust_region_least_squares_chained_rosenbrock(analytic):
+    """TrustRegion / TrustRegion_basic (NO.f90:1728, 2348; hpp:358-366): f'(x) = 0 for the chained Rosenbrock residuals
+    r = (10 (x_{i+1} - x_i^2), 1 - x_i), M = 2 (N - 1) >= N, with the analytical Jacobian and with central differences;
+    the solution is x = 1 with zero residual.  Also with bounds that cut the solution off: the projected optimum."""
+    FL = _fl()
+    n = 12
+    m = 2 * (n - 1)
+
+    def res(r, x, M, N):
+        for i in range(n - 1):
+            r[2 * i] = 10.0 * (x[i + 1] - x[i] * x[i])
+            r[2 * i + 1] = 1.0 - x[i]
+
+    def jac(J, x, M, N):  # column-major M x N
+        for k in range(m * n):
+            J[k] = 0.0
+        for i in range(n - 1):
+            J[i * m + 2 * i] = -20.0 * x[i]
+            J[(i + 1) * m + 2 * i] = 10.0
+            J[i * m + 2 * i + 1] = -1.0
+        return 0
+    r_cb, j_cb = RES_CB(res), JAC_CB(jac)
+    dp = C.POINTER(C.c_double)
+    x = np.full(n, -1.2)
+    x[1::2] = 1.0
+    M_, N_ = C.c_int(m), C.c_int(n)
+    w, mi, ms = C.c_int32(0), C.c_int(200), C.c_int(50)
+    pr, mn = C.c_double(1e-10), C.c_double(1e-15)
+    if analytic:
+        FL.__nonlinearoptimization_MOD_trustregion_basic(r_cb, j_cb, x.ctypes.data_as(dp), C.byref(M_), C.byref(N_), C.byref(w),
+                                                         C.byref(mi), C.byref(ms), C.byref(pr), C.byref(mn))
+    else:  # Fortran-style general routine: Jacobian absent (numerical), the other optionals absent too
+        FL.__nonlinearoptimization_MOD_trustregion(r_cb, x.ctypes.data_as(dp), C.byref(M_), C.byref(N_), None, None, None,
+                                                   C.byref(w), None, None, C.byref(pr), None)
+    assert np.max(np.abs(x - 1.0)) < 1e-8
+    lo, up = np.full(n, -2.0), np.full(n, 0.5)
+    x = np.full(n, -1.2)
+    x[1::2] = 0.3
+    FL.__nonlinearoptimization_MOD_trustregion(r_cb, x.ctypes.data_as(dp), C.byref(M_), C.byref(N_), j_cb if analytic else None,
+                                               lo.ctypes.data_as(dp), up.ctypes.data_as(dp), C.byref(w), C.byref(mi),
+                                               C.byref(ms), C.byref(pr), C.byref(mn))
+    assert np.all(x <= 0.5 + 1e-15) and np.all(x >= -2.0)
+    rr = (C.c_double * m)()
+    res(rr, x, None, None)
+    x0 = np.full(n, -1.2)
+    x0[1::2] = 0.3
+    r0 = (C.c_double * m)()
+    res(r0, x0, None, None)
+    assert sum(v * v for v in rr) < 0.5 * sum(v * v for v in r0)

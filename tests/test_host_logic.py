@@ -32,7 +32,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     # the reference's own mangled entry points (include/fl_legacy.h; cpp/NonlinearOptimization.hpp:278-393)
     leg = open(os.path.join(ROOT, "include", "fl_legacy.h")).read()
     lnames = sorted(set(re.findall(r"\b(__nonlinearoptimization_MOD_[a-z_]+|nonlinearoptimization_mp_[a-z_]+_)\s*\(", leg)))
-    assert len(lnames) == 24  # 8 routines + 4 line searchers, gfortran and ifort manglings
+    assert len(lnames) == 28  # 10 routines + 4 line searchers, gfortran and ifort manglings
     for nme in lnames:
         assert hasattr(lib, nme), nme
     # LinearAlgebra symbols the reference's C++ header binds (cpp/FortranLibrary.hpp:48-63)
