@@ -281,10 +281,12 @@ FL.fl_rci_results.argtypes = [_vp, _dp, _dp, _ip, _ip, _ip, _ip]
 FL.fl_rci_destroy.argtypes = [_vp]
 
 
-def minimize_rci(solver, x, fun, options=None, max_steps=10000000, **kw):
+def minimize_rci(solver, x, fun, options=None, max_steps=10000000, check_every=8, **kw):
     """Batched minimisation of a user objective by reverse communication (fl_rci_*): `fun(x)` returns
     (f[batch], g[batch, n]) torch CUDA tensors for the whole batch; x is updated in place.  The solver
-    machines run in the HIP kernels; only the objective is the caller's.  solver: SD | CG | LBFGS_ | BFGS_."""
+    machines run in the HIP kernels; only the objective is the caller's.  solver: SD | CG | LBFGS_ | BFGS_.
+    The request vector is brought to the host only every `check_every` steps (a step on a finished batch is a
+    no-op on the device), and f, g are handed over without a copy when they are contiguous float64."""
     import torch
     o = options if options is not None else default_options(solver, **kw)
     B, n, out = _prep(x, None, None)
@@ -292,15 +294,17 @@ def minimize_rci(solver, x, fun, options=None, max_steps=10000000, **kw):
     _check(FL.fl_rci_create(C.byref(h), solver, B, n, C.byref(o), _stream()), "fl_rci_create")
     try:
         req = torch.empty(B, dtype=torch.int32, device=x.device)
-        f = torch.zeros(B, dtype=torch.float64, device=x.device)
-        g = torch.zeros(B, n, dtype=torch.float64, device=x.device)
         _check(FL.fl_rci_step(h, _ptr(x), None, None, _ptr(req)), "fl_rci_step")
         steps = 0
-        while bool((req != 0).any()) and steps < max_steps:
+        while steps < max_steps:
+            if steps % check_every == 0 and not bool((req != 0).any()):
+                break
             fn, gn = fun(x)
-            f.copy_(fn)
-            g.copy_(gn)
-            _check(FL.fl_rci_step(h, _ptr(x), _ptr(f), _ptr(g), _ptr(req)), "fl_rci_step")
+            if fn.dtype != torch.float64 or not fn.is_contiguous():
+                fn = fn.to(torch.float64).contiguous()
+            if gn.dtype != torch.float64 or not gn.is_contiguous():
+                gn = gn.to(torch.float64).contiguous()
+            _check(FL.fl_rci_step(h, _ptr(x), _ptr(fn), _ptr(gn), _ptr(req)), "fl_rci_step")
             steps += 1
         _check(FL.fl_rci_results(h, _ptr(out["f"]), _ptr(out["gg"]), _ptr(out["iters"]), _ptr(out["status"]),
                                  _ptr(out["nf"]), _ptr(out["ng"])), "fl_rci_results")
