@@ -5,7 +5,8 @@
 // pairs (c*1024 + t)*2 + {0,1}, c = 0..nslot-1 -- the register path's layout with EPT = 2*nslot -- and sums its
 // terms in that order, then the 16 waves left to right, so the oracle replays it with threads = 1024,
 // ept = 2*nslot (fl_reduction_geometry reports both).  SteepestDescent (NO.f90:55-188), ConjugateGradient
-// (193-394), L-BFGS (398-625); the dense solvers (BFGS, NewtonRaphson) stay on the register path.
+// (193-394), L-BFGS (398-625), and BFGS with quasi-Newton updates only (632-1022, ExactStep <= 0) up to n = 16384;
+// NewtonRaphson and the exact-Hessian refresh (dense Cholesky) stay on the register path.
 // Every element is only ever touched by its own thread, so passes need no barrier besides the reductions --
 // except Rosenbrock's neighbour reads, which follow a __syncthreads() after x has been written.
 // The L-BFGS recursion is fused pass-wise: the axpy of step j and the dot product of step j+1 share one pass.
@@ -15,8 +16,9 @@
 namespace fl {
 
 template <int OBJ, int METHOD> struct BigSolver {
-    static_assert(METHOD == FL_SOLVER_SD || METHOD == FL_SOLVER_CG || METHOD == FL_SOLVER_LBFGS,
-                  "vectors-in-HBM path: SD, CG, L-BFGS");
+    static_assert(METHOD == FL_SOLVER_SD || METHOD == FL_SOLVER_CG || METHOD == FL_SOLVER_LBFGS ||
+                      METHOD == FL_SOLVER_BFGS,
+                  "vectors-in-HBM path: SD, CG, L-BFGS, BFGS (quasi-Newton updates only)");
     static constexpr int NW = 16, T = 1024;
     static constexpr bool NEEDS_G0 = (METHOD != FL_SOLVER_SD);
     static constexpr int ROWS = 4; // p, x0, g0, g per problem
@@ -24,7 +26,12 @@ template <int OBJ, int METHOD> struct BigSolver {
     static constexpr int L_RED = 0;
     static constexpr int L_RHO = L_RED + 2 * Reducer<NW>::NVMAX * NW;
     static constexpr int L_ALPHA = L_RHO + FL_MAX_MEMORY;
-    static constexpr int LDS_TOTAL = L_ALPHA + FL_MAX_MEMORY;
+    // BFGS (n <= BF_MAX_N): inverse Hessian [n][npad] in HBM, rank-2 updates deferred exactly like
+    // Solver::direction_bfgs_deferred (pending updates as vectors, folded every BF_DEFER-th iteration; oracle
+    // update_form 100 + BF_DEFER); L_STAGE: s_l[j], q_l[j] of BF_FOLD_COLS columns while folding
+    static constexpr int BF_DEFER = FL_BFGS_DEFER, BF_FOLD_COLS = 128, BF_MAX_SLOTS = 8, BF_MAX_N = BF_MAX_SLOTS * 2 * T;
+    static constexpr int L_STAGE = L_ALPHA + FL_MAX_MEMORY;
+    static constexpr int LDS_TOTAL = L_STAGE + (METHOD == FL_SOLVER_BFGS ? 2 * BF_DEFER * BF_FOLD_COLS + 4 : 0);
     static constexpr int RCI_SCALARS = 48;
 
     const SolveArgs &A;
@@ -41,6 +48,8 @@ template <int OBJ, int METHOD> struct BigSolver {
     int iters, nf, ng, status, phase, pending;
     int recent, cnt;
     double yy_recent, rho_recent;
+    int main_it, h_valid, ndef, h_ident; // BFGS (names as in Solver)
+    double a_id;
     LineSearch ls;
     enum { PH_INIT = 0, PH_LS = 1, PH_DONE = 2 };
 
@@ -60,8 +69,11 @@ template <int OBJ, int METHOD> struct BigSolver {
         x0 = rows + npad;
         g0 = rows + 2 * npad;
         g = rows + 3 * npad;
-        hist = (METHOD == FL_SOLVER_LBFGS) ? A.hist + (size_t)prob * (size_t)(2 * A.mem) * npad : nullptr;
+        hist = nullptr;
+        if constexpr (METHOD == FL_SOLVER_LBFGS) hist = A.hist + (size_t)prob * (size_t)(2 * A.mem) * npad;
+        if constexpr (METHOD == FL_SOLVER_BFGS) hist = A.hist + (size_t)prob * bfgs_rows(n) * npad; // H, pending s_l q_l, y
     }
+    __host__ __device__ static size_t bfgs_rows(int n) { return (size_t)n + 2 * BF_DEFER + 1; }
 
     // ---- element pairs
     __device__ __forceinline__ int e_of(int c) const { return (c * T + tid) << 1; }
@@ -111,6 +123,8 @@ template <int OBJ, int METHOD> struct BigSolver {
         cnt = 0;
         yy_recent = rho_recent = 0.0;
         fnew = gg = pp = phid = phidold = a = 0.0;
+        main_it = h_valid = ndef = h_ident = 0;
+        a_id = 0.0;
         phase = PH_INIT;
         pending = 0;
     }
@@ -244,6 +258,7 @@ template <int OBJ, int METHOD> struct BigSolver {
     __device__ __forceinline__ int max_linesearches() const
     {
         if constexpr (METHOD == FL_SOLVER_LBFGS) return A.mem + A.maxit;
+        if constexpr (METHOD == FL_SOLVER_BFGS) return 0x7fffffff; // counted by main_it in begin_linesearch
         return A.maxit;
     }
     __device__ __forceinline__ int finished()
@@ -264,6 +279,16 @@ template <int OBJ, int METHOD> struct BigSolver {
     {
         int fused = A.fused;
         if constexpr (METHOD == FL_SOLVER_LBFGS) fused = fused && (iters >= A.mem); // NO.f90:448-460, 486-498
+        if constexpr (METHOD == FL_SOLVER_BFGS) { // main loop do iIteration=1,maxit (NO.f90:717-929); the first step precedes it
+            if (h_valid) {
+                if (main_it >= A.maxit) {
+                    status = FL_STATUS_MAXIT;
+                    return finished();
+                }
+                ++main_it;
+            }
+            fused = fused && h_valid;
+        }
         for (int c = 0; c < nslot; ++c) { // xold=x; fdold=fdnew
             const int e = e_of(c);
             double u, v;
@@ -319,6 +344,9 @@ template <int OBJ, int METHOD> struct BigSolver {
             a = a * phidold / phid;
         } else if constexpr (METHOD == FL_SOLVER_CG) {
             direction_cg();
+        } else if constexpr (METHOD == FL_SOLVER_BFGS) {
+            direction_bfgs();
+            h_valid = 1;
         } else {
             direction_lbfgs();
         }
@@ -491,10 +519,203 @@ template <int OBJ, int METHOD> struct BigSolver {
         a = 1.0;
     }
 
+    // ---------------------------------------------------------------- BFGS, deferred rank-2 updates (NO.f90:996-1015, 711-715)
+    __device__ __forceinline__ double *def_row(int r) const { return hist + ((size_t)n + r) * npad; }
+    __device__ __forceinline__ void direction_bfgs()
+    {
+        double *H = hist, *yrow = def_row(2 * BF_DEFER);
+        double *drho = lds + L_RHO, *dcs = drho + BF_DEFER; // rho_l, cs_l of the pending updates
+        // s, y (y also as a row: the matvec reads y_j per column)
+        double r1[1] = {0.0};
+        for (int c = 0; c < nslot; ++c) {
+            const int e = e_of(c);
+            double xa, xb, oa, ob, ga, gb, ha, hb;
+            ldu(x, e, xa, xb);
+            ldw(x0, e, oa, ob);
+            ldw(g, e, ga, gb);
+            ldw(g0, e, ha, hb);
+            const double ya = ga - ha, yb = gb - hb;
+            stw(yrow, e, ya, yb);
+            acc2(r1[0], c, ya * (xa - oa), yb * (xb - ob));
+        }
+        R.run(r1);
+        const double rho = uni(1.0 / r1[0]);
+        if (!h_valid) {
+            ndef = 0;
+            h_ident = 1;
+            a_id = a;
+        }
+        double q[2 * BF_MAX_SLOTS], w[2 * BF_MAX_SLOTS];
+        if (h_ident) {
+#pragma unroll
+            for (int c = 0; c < BF_MAX_SLOTS; ++c) {
+                if (c < nslot) {
+                    const int e = e_of(c);
+                    double ya, yb, ga, gb;
+                    ldw(yrow, e, ya, yb);
+                    ldw(g, e, ga, gb);
+                    q[2 * c] = a_id * ya;
+                    q[2 * c + 1] = a_id * yb;
+                    w[2 * c] = a_id * ga;
+                    w[2 * c + 1] = a_id * gb;
+                }
+            }
+        } else {
+            __syncthreads(); // y row complete
+#pragma unroll
+            for (int k = 0; k < 2 * BF_MAX_SLOTS; ++k) q[k] = w[k] = 0.0;
+            for (int j = 0; j < n; ++j) { // one read pass over H: q = H y, w = H g
+                const double yj = yrow[j], gj = g[j];
+                const double *col = H + (size_t)j * npad;
+#pragma unroll
+                for (int c = 0; c < BF_MAX_SLOTS; ++c) {
+                    if (c < nslot) {
+                        double ha, hb;
+                        ldw(col, e_of(c), ha, hb);
+                        q[2 * c] = q[2 * c] + ha * yj;
+                        q[2 * c + 1] = q[2 * c + 1] + hb * yj;
+                        w[2 * c] = w[2 * c] + ha * gj;
+                        w[2 * c + 1] = w[2 * c + 1] + hb * gj;
+                    }
+                }
+            }
+        }
+        for (int l = 0; l < ndef; ++l) { // corrections of the pending updates, oldest first
+            const double *S = def_row(2 * l), *Q = def_row(2 * l + 1);
+            double r[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int c = 0; c < nslot; ++c) {
+                const int e = e_of(c);
+                double sa, sb, qa, qb, ya, yb, ga, gb;
+                ldw(S, e, sa, sb);
+                ldw(Q, e, qa, qb);
+                ldw(yrow, e, ya, yb);
+                ldw(g, e, ga, gb);
+                acc2(r[0], c, sa * ya, sb * yb);
+                acc2(r[1], c, qa * ya, qb * yb);
+                acc2(r[2], c, sa * ga, sb * gb);
+                acc2(r[3], c, qa * ga, qb * gb);
+            }
+            R.run(r);
+            const double rl = drho[l], cl = dcs[l];
+#pragma unroll
+            for (int c = 0; c < BF_MAX_SLOTS; ++c) {
+                if (c < nslot) {
+                    const int e = e_of(c);
+                    double sa, sb, qa, qb;
+                    ldw(S, e, sa, sb);
+                    ldw(Q, e, qa, qb);
+                    const double rqa = rl * qa, rqb = rl * qb, rsa = rl * sa, rsb = rl * sb, cca = cl * sa, ccb = cl * sb;
+                    q[2 * c] = q[2 * c] - rqa * r[0] - rsa * r[1] + cca * r[0];
+                    q[2 * c + 1] = q[2 * c + 1] - rqb * r[0] - rsb * r[1] + ccb * r[0];
+                    w[2 * c] = w[2 * c] - rqa * r[2] - rsa * r[3] + cca * r[2];
+                    w[2 * c + 1] = w[2 * c + 1] - rqb * r[2] - rsb * r[3] + ccb * r[2];
+                }
+            }
+        }
+        double r3[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int c = 0; c < BF_MAX_SLOTS; ++c) {
+            if (c < nslot) {
+                const int e = e_of(c);
+                double ya, yb, ga, gb, xa, xb, oa, ob;
+                ldw(yrow, e, ya, yb);
+                ldw(g, e, ga, gb);
+                ldu(x, e, xa, xb);
+                ldw(x0, e, oa, ob);
+                acc2(r3[0], c, ya * q[2 * c], yb * q[2 * c + 1]);
+                acc2(r3[1], c, (xa - oa) * ga, (xb - ob) * gb);
+                acc2(r3[2], c, q[2 * c] * ga, q[2 * c + 1] * gb);
+            }
+        }
+        R.run(r3);
+        const double cs = uni(rho * rho * r3[0] + rho);
+        double r4[2] = {0.0, 0.0};
+        double *Sn = def_row(2 * ndef), *Qn = def_row(2 * ndef + 1);
+#pragma unroll
+        for (int c = 0; c < BF_MAX_SLOTS; ++c) {
+            if (c < nslot) {
+                const int e = e_of(c);
+                double ga, gb, xa, xb, oa, ob;
+                ldw(g, e, ga, gb);
+                ldu(x, e, xa, xb);
+                ldw(x0, e, oa, ob);
+                const double sa = xa - oa, sb = xb - ob;
+                const double pa = -(w[2 * c] - (rho * q[2 * c]) * r3[1] - (rho * sa) * r3[2] + (cs * sa) * r3[1]);
+                const double pb = -(w[2 * c + 1] - (rho * q[2 * c + 1]) * r3[1] - (rho * sb) * r3[2] + (cs * sb) * r3[1]);
+                stw(p, e, pa, pb);
+                stw(Sn, e, sa, sb);
+                stw(Qn, e, q[2 * c], q[2 * c + 1]);
+                acc2(r4[0], c, ga * pa, gb * pb);
+                acc2(r4[1], c, pa * pa, pb * pb);
+            }
+        }
+        if (tid == 0) {
+            drho[ndef] = rho;
+            dcs[ndef] = cs;
+        }
+        ++ndef;
+        R.run(r4); // (its barrier also publishes rho_l, cs_l and the new rows)
+        if (ndef == BF_DEFER) bfgs_fold();
+        phid = r4[0];
+        pp = r4[1];
+        a = 1.0;
+    }
+    __device__ __forceinline__ void bfgs_fold()
+    {
+        constexpr int J = BF_DEFER, CB = BF_FOLD_COLS;
+        double *H = hist, *stage = lds + L_STAGE;
+        const double *drho = lds + L_RHO, *dcs = drho + J;
+        __syncthreads();
+        for (int c = 0; c < nslot; ++c) {
+            const int e = e_of(c);
+            double rq[J][2], rs[J][2], cf[J][2];
+#pragma unroll
+            for (int l = 0; l < J; ++l) {
+                double sa, sb, qa, qb;
+                ldw(def_row(2 * l), e, sa, sb);
+                ldw(def_row(2 * l + 1), e, qa, qb);
+                const double rl = drho[l], cl = dcs[l];
+                rq[l][0] = rl * qa; rq[l][1] = rl * qb;
+                rs[l][0] = rl * sa; rs[l][1] = rl * sb;
+                cf[l][0] = cl * sa; cf[l][1] = cl * sb;
+            }
+            for (int jb = 0; jb < n; jb += CB) {
+                __syncthreads();
+                for (int i = tid; i < 2 * J * CB; i += T) {
+                    const int row = i / CB, col = i - row * CB;
+                    stage[i] = (jb + col < n) ? def_row(row)[jb + col] : 0.0;
+                }
+                __syncthreads();
+                const int jend = (n - jb < CB) ? n - jb : CB;
+                for (int jj = 0; jj < jend; ++jj) {
+                    const int j = jb + jj;
+                    double *hp = H + (size_t)j * npad;
+                    double ha, hb;
+                    if (h_ident) {
+                        ha = (e == j) ? a_id : 0.0;
+                        hb = (e + 1 == j) ? a_id : 0.0;
+                    } else {
+                        ldw(hp, e, ha, hb);
+                    }
+#pragma unroll
+                    for (int l = 0; l < J; ++l) {
+                        const double sj = stage[(2 * l) * CB + jj], qj = stage[(2 * l + 1) * CB + jj];
+                        ha = ha - rq[l][0] * sj - rs[l][0] * qj + cf[l][0] * sj;
+                        hb = hb - rq[l][1] * sj - rs[l][1] * qj + cf[l][1] * sj;
+                    }
+                    stw(hp, e, ha, hb);
+                }
+            }
+        }
+        __syncthreads();
+        h_ident = 0;
+        ndef = 0;
+    }
+
     // ---------------------------------------------------------------- reverse communication: park / resume
     __device__ __forceinline__ void save(double *sc, double *rho, double fv_c, double pv_c)
     {
-        if constexpr (METHOD == FL_SOLVER_LBFGS) {
+        if constexpr (METHOD == FL_SOLVER_LBFGS || METHOD == FL_SOLVER_BFGS) { // rho ring / rho_l, cs_l of pending updates
             __syncthreads();
             if (tid < FL_MAX_MEMORY) rho[tid] = lds[L_RHO + tid];
         }
@@ -509,11 +730,13 @@ template <int OBJ, int METHOD> struct BigSolver {
             int *iq = reinterpret_cast<int *>(sc + 32);
             *iq++ = iters; *iq++ = nf; *iq++ = ng; *iq++ = status; *iq++ = phase; *iq++ = pending;
             *iq++ = recent; *iq++ = cnt; *iq++ = ls.st; *iq++ = ls.zret; *iq++ = ls.fused;
+            *iq++ = main_it; *iq++ = h_valid; *iq++ = ndef; *iq++ = h_ident;
+            sc[29] = a_id;
         }
     }
     __device__ __forceinline__ void load(const double *sc, const double *rho, double &fv_c, double &pv_c)
     {
-        if constexpr (METHOD == FL_SOLVER_LBFGS) {
+        if constexpr (METHOD == FL_SOLVER_LBFGS || METHOD == FL_SOLVER_BFGS) {
             if (tid < FL_MAX_MEMORY) lds[L_RHO + tid] = rho[tid];
             __syncthreads();
         }
@@ -527,6 +750,8 @@ template <int OBJ, int METHOD> struct BigSolver {
         const int *iq = reinterpret_cast<const int *>(sc + 32);
         iters = *iq++; nf = *iq++; ng = *iq++; status = *iq++; phase = *iq++; pending = *iq++;
         recent = *iq++; cnt = *iq++; ls.st = *iq++; ls.zret = *iq++; ls.fused = *iq++;
+        main_it = *iq++; h_valid = *iq++; ndef = *iq++; h_ident = *iq++;
+        a_id = sc[29];
         // every wave has read the parked scalars before thread 0 may overwrite them in save(): a step that only
         // takes an objective value has no other barrier
         __syncthreads();

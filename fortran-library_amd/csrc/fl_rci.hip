@@ -202,6 +202,7 @@ static void launch_rci_big(Rci *h, const double *f, const double *g, int32_t *re
     switch (h->solver) {
     case FL_SOLVER_SD: FL_RCI(FL_SOLVER_SD); break;
     case FL_SOLVER_CG: FL_RCI(FL_SOLVER_CG); break;
+    case FL_SOLVER_BFGS: FL_RCI(FL_SOLVER_BFGS); break;
     default: FL_RCI(FL_SOLVER_LBFGS); break;
     }
 #undef FL_RCI
@@ -233,8 +234,12 @@ int fl_rci_create(fl_rci **out, int solver, int batch, int n, const fl_options *
     if (opt->cg_method != FL_CG_DY && opt->cg_method != FL_CG_PR) return FL_ERR_INVALID_ARGUMENT;
     int threads = 0, ept = 0;
     if (fl_reduction_geometry(n, &threads, &ept) != FL_OK) return FL_ERR_UNSUPPORTED_SIZE;
-    // beyond the register path (1024 threads): SD / CG / L-BFGS only, the dense solvers need n <= 4096
-    if (threads == 1024 && (solver == FL_SOLVER_BFGS || solver == FL_SOLVER_NEWTON)) return FL_ERR_UNSUPPORTED_SIZE;
+    // beyond the register path (1024 threads): SD / CG / L-BFGS, and BFGS with quasi-Newton updates only up to
+    // n = 16384; NewtonRaphson and the exact-Hessian refresh (dense Cholesky) need n <= 4096
+    if (threads == 1024 && (solver == FL_SOLVER_NEWTON ||
+                            (solver == FL_SOLVER_BFGS && (opt->exact_step > 0 ||
+                                                          n > fl::BigSolver<FL_OBJ_EXTERNAL, FL_SOLVER_BFGS>::BF_MAX_N))))
+        return FL_ERR_UNSUPPORTED_SIZE;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FL_ERR_NO_DEVICE;
     fl_rci *h = new (std::nothrow) fl_rci();
@@ -630,7 +635,12 @@ void __nonlinearoptimization_MOD_bfgs(f_cb f, fd_cb fd, double *x, const int *di
     fl_options o;
     legacy_options(o, FL_SOLVER_BFGS, Strong, MaxIteration, Precision, MinStepLength, WolfeConst1, WolfeConst2,
                    Increment, f_fd);
-    const int freq = ExactStep ? *ExactStep : 20;
+    int freq = ExactStep ? *ExactStep : 20;
+    if (freq > 0 && *dim > 4096) { // the exact inverse Hessian is a dense Cholesky: register path only
+        if (warn_of(Warning))
+            std::printf(" BFGS (MI355X): dim > 4096, the exact Hessian refresh is skipped (quasi-Newton updates only)\n");
+        freq = 0;
+    }
     o.exact_step = freq;
     HostObjective ob = host_objective(f, fd, f_fd);
     if (freq > 0 && fdd) {

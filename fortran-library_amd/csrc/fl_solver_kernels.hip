@@ -78,6 +78,7 @@ template <int OBJ> static hipError_t launch_big_m(int method, const SolveArgs &A
     switch (method) {
     case FL_SOLVER_SD: FL_BIG(FL_SOLVER_SD); break;
     case FL_SOLVER_CG: FL_BIG(FL_SOLVER_CG); break;
+    case FL_SOLVER_BFGS: FL_BIG(FL_SOLVER_BFGS); break;
     default: FL_BIG(FL_SOLVER_LBFGS); break;
     }
 #undef FL_BIG
@@ -186,7 +187,10 @@ static int solve(int method, int objective, int batch, int n, double *x, const d
     if (!select_geometry(n, g)) {
         // beyond the register path: SD / CG / L-BFGS continue with vectors in HBM; the dense solvers and the
         // augmented Lagrangian do not
-        if (aug || (method != FL_SOLVER_SD && method != FL_SOLVER_CG && method != FL_SOLVER_LBFGS)) return FL_ERR_UNSUPPORTED_SIZE;
+        if (aug || method == FL_SOLVER_NEWTON) return FL_ERR_UNSUPPORTED_SIZE;
+        // BFGS: quasi-Newton updates only (the exact-Hessian refresh is a dense Cholesky), H [n][npad] up to n = 16384
+        if (method == FL_SOLVER_BFGS && (opt->exact_step > 0 || n > BigSolver<FL_OBJ_QUARTIC, FL_SOLVER_BFGS>::BF_MAX_N))
+            return FL_ERR_UNSUPPORTED_SIZE;
         if (!select_big_geometry(n, g)) return FL_ERR_UNSUPPORTED_SIZE;
         big = true;
     }
@@ -248,13 +252,16 @@ static int solve(int method, int objective, int batch, int n, double *x, const d
         // workspace argument in the C ABI: their four rows come from the stream-ordered allocator
         const size_t npad = (size_t)g.nw * 64 * g.ept, rows_bytes = (size_t)batch * 4 * npad * sizeof(double);
         double *rows = nullptr;
+        const bool own_rows = (method == FL_SOLVER_SD || method == FL_SOLVER_CG);
         if (method == FL_SOLVER_LBFGS) {
             rows = static_cast<double *>(ws) + (size_t)batch * 2 * (size_t)A.mem * npad;
+        } else if (method == FL_SOLVER_BFGS) {
+            rows = static_cast<double *>(ws) + (size_t)batch * BigSolver<FL_OBJ_QUARTIC, FL_SOLVER_BFGS>::bfgs_rows(n) * npad;
         } else if (hipMallocAsync((void **)&rows, rows_bytes, st) != hipSuccess) {
             return FL_ERR_WORKSPACE;
         }
         hipError_t e = launch_big(objective, method, A, rows, st);
-        if (method != FL_SOLVER_LBFGS) (void)hipFreeAsync(rows, st);
+        if (own_rows) (void)hipFreeAsync(rows, st);
         return e == hipSuccess ? FL_OK : FL_ERR_NO_DEVICE;
     }
     hipError_t e = launch(g, objective, method, aug != nullptr, A, st);
@@ -289,7 +296,9 @@ size_t fl_workspace_bytes_for(int solver, int batch, int n, const fl_options *op
     if (!opt) return 0;
     if (solver == FL_SOLVER_BFGS || solver == FL_SOLVER_NEWTON) {
         fl::GeoSel g;
-        if (batch <= 0 || !fl::select_geometry(n, g)) return 0;
+        if (batch <= 0) return 0;
+        if (!fl::select_geometry(n, g)) return fl_workspace_bytes(solver, batch, n, 0); // beyond the register path
+
         const size_t npad = (size_t)(g.nw * 64 * g.ept);
         if (solver == FL_SOLVER_NEWTON) return (size_t)batch * (size_t)n * npad * sizeof(double);
         // H (+ Hessian / factor and inverse factor with ExactStep > 0) + the rows of the deferred updates (n > 1024)
@@ -321,10 +330,14 @@ size_t fl_workspace_bytes(int solver, int batch, int n, int memory)
 {
     fl::GeoSel g;
     if (batch <= 0) return 0;
-    if (!fl::select_geometry(n, g)) { // vectors-in-HBM path: the ring plus the four vector rows (L-BFGS only)
-        if (solver != FL_SOLVER_LBFGS || !fl::select_big_geometry(n, g)) return 0;
+    if (!fl::select_geometry(n, g)) { // vectors-in-HBM path: the ring / the inverse Hessian plus the four vector rows
+        if (!fl::select_big_geometry(n, g)) return 0;
+        const size_t npad = (size_t)g.nw * 64 * g.ept;
+        using BB = fl::BigSolver<FL_OBJ_QUARTIC, FL_SOLVER_BFGS>;
+        if (solver == FL_SOLVER_BFGS && n <= BB::BF_MAX_N) return (size_t)batch * (BB::bfgs_rows(n) + 4) * npad * sizeof(double);
+        if (solver != FL_SOLVER_LBFGS) return 0;
         const size_t mem = memory > 1 ? (size_t)memory : 1;
-        return (size_t)batch * (2 * mem + 4) * ((size_t)g.nw * 64 * g.ept) * sizeof(double);
+        return (size_t)batch * (2 * mem + 4) * npad * sizeof(double);
     }
     const size_t npad = (size_t)(g.nw * 64 * g.ept);
     if (solver == FL_SOLVER_LBFGS) {

@@ -39,8 +39,8 @@ extern "C" {
 
 #define FL_OK 0
 #define FL_ERR_INVALID_ARGUMENT (-1) /* NULL pointer, batch/n <= 0, unknown enum */
-#define FL_ERR_UNSUPPORTED_SIZE (-2) /* Memory > FL_MAX_MEMORY; n > 4096 for the dense solvers (BFGS, NewtonRaphson) */
-                                     /* and the augmented Lagrangian; n > 2^27 for SD / CG / L-BFGS                  */
+#define FL_ERR_UNSUPPORTED_SIZE (-2) /* Memory > FL_MAX_MEMORY; n > 4096 for NewtonRaphson, BFGS with exact_step > 0 and */
+                                     /* the augmented Lagrangian; n > 16384 for BFGS; n > 2^27 for SD / CG / L-BFGS      */
 #define FL_ERR_WORKSPACE (-3)        /* workspace missing or too small */
 #define FL_ERR_NO_DEVICE (-4)        /* no HIP device / kernel launch failed */
 
@@ -96,8 +96,9 @@ void fl_default_options(fl_options *opt, int solver);
  * elements, then the fixed 64-lane tree of csrc/fl_reduce.hpp (lanes l and l+32,
  * then l and l+16, then mirror steps inside a row of 16), then waves left to right -- the order
  * tests replay on the CPU to compare bit for bit.  n <= 4096: the problem's vectors live
- * in registers (threads <= 512, ept <= 8).  n > 4096 (SD / CG / L-BFGS): the same machine with
- * its vectors in HBM, threads = 1024, ept = 2*ceil(ceil(n/2)/1024) (csrc/fl_big.hpp).
+ * in registers (threads <= 512, ept <= 8).  n > 4096 (SD / CG / L-BFGS; BFGS with quasi-Newton
+ * updates only up to 16384): the same machine with its vectors in HBM, threads = 1024,
+ * ept = 2*ceil(ceil(n/2)/1024) (csrc/fl_big.hpp).
  * FL_ERR_UNSUPPORTED_SIZE beyond 2^27. */
 int fl_reduction_geometry(int n, int *threads, int *ept);
 

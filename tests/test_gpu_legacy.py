@@ -638,3 +638,24 @@ def test_trust_region_least_squares_chained_rosenbrock(analytic):
     r0 = (C.c_double * m)()
     res(r0, x0, None, None)
     assert sum(v * v for v in rr) < 0.5 * sum(v * v for v in r0)
+
+
+def test_legacy_bfgs_beyond_the_register_path_n4500():
+    """__nonlinearoptimization_MOD_bfgs with dim > 4096 and ExactStep = 0: host callbacks, inverse Hessian in HBM,
+    deferred rank-2 updates through the reverse-communication kernel (pending updates parked between launches)."""
+    FL = _fl()
+    n = 4500
+    rng = np.random.default_rng(45)
+    x0 = 1.0 + 0.1 * rng.uniform(-1, 1, n)
+    f, fd, ffd, cnt, (T, E), _ = _callbacks(O.ROSENBROCK, n)
+    assert T == 1024
+    dim = C.c_int(n)
+    dp = C.POINTER(C.c_double)
+    x = x0.copy()
+    vals, refs = _common(maxit=11, precision=1e-9)
+    es = C.c_int(0)
+    FL.__nonlinearoptimization_MOD_bfgs(f, fd, x.ctypes.data_as(dp), C.byref(dim), None, C.byref(es), ffd, *refs)
+    ref = O.solve_batch(O.BFGS, O.ROSENBROCK, x0, opts=O.defaults(maxit=11, precision=1e-9, exact_step=0), use_ffd=True,
+                        bfgs_form=108, sum_mode=O.TREE, threads=T, ept=E)
+    assert np.array_equal(x, ref["x"][0])
+    assert cnt["f"] + cnt["f_fd"] == ref["nf"][0] and cnt["fd"] + cnt["f_fd"] == ref["ng"][0]

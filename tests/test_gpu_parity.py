@@ -208,11 +208,35 @@ def test_beyond_the_register_path_vectors_in_hbm_bitexact(solver, kw, kind, n):
     _assert_bitexact(g, o)
 
 
+@pytest.mark.parametrize("kind,n,kw", [(O.DIAGQUAD, 4200, {"MaxIteration": 19}), (O.ROSENBROCK, 5001, {"MaxIteration": 10}),
+                                       (O.QUARTIC, 6200, {"MaxIteration": 9, "f_fd": True})])
+def test_bfgs_beyond_the_register_path_bitexact(kind, n, kw):
+    """dense BFGS for n > 4096 (quasi-Newton updates only): inverse Hessian and vectors in HBM, the deferred rank-2
+    form (csrc/fl_big.hpp direction_bfgs) -- the oracle's update_form 108 in the 1024-thread summation order,
+    across zero, one and two folds."""
+    NLO = _nlo()
+    T, E = NLO.reduction_geometry(n)
+    assert T == 1024
+    rng = np.random.default_rng(n)
+    B = 2
+    if kind == O.DIAGQUAD:
+        d, b = _quads(B, n, 10.0, 300.0, n)
+        x0 = np.zeros((B, n))
+    else:
+        d = b = None
+        x0 = (1.0 + 0.1 * rng.uniform(-1, 1, (B, n))) if kind == O.ROSENBROCK else rng.uniform(0.2, 1.0, (B, n))
+    g = _gpu_bfgs(kind, x0, d, b, **kw)
+    o = _oracle_bfgs(kind, x0, d, b, 1, O.TREE, kw)
+    _assert_bitexact(g, o)
+
+
 def test_argument_errors_and_no_cpu_fallback():
     NLO = _nlo()
     x = torch.zeros(2, 5000, dtype=torch.float64, device="cuda:0")
-    with pytest.raises(NLO.FLError):  # the dense solvers stay on the register path: n <= 4096
-        NLO.BFGS(O.ROSENBROCK, x, ExactStep=0)
+    with pytest.raises(NLO.FLError):  # the exact-Hessian refresh (dense Cholesky) stays on the register path: n <= 4096
+        NLO.BFGS(O.ROSENBROCK, x, ExactStep=5)
+    with pytest.raises(NLO.FLError):
+        NLO.NewtonRaphson(O.ROSENBROCK, x)
     x = torch.zeros(2, 16, dtype=torch.float64, device="cuda:0")
     with pytest.raises(NLO.FLError):  # quadratic data missing
         NLO.LBFGS(O.DIAGQUAD, x)
