@@ -65,6 +65,7 @@ def main():
     ap.add_argument("configs", nargs="*", default=["c2", "c3", "c4", "c5"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--c4-batch", type=int, default=1024)
+    ap.add_argument("--c4-iterations", type=int, default=20)
     args = ap.parse_args()
     cores = host_cores()
     host = f"{cores} cores of {cpu_model()}"
@@ -127,7 +128,7 @@ def main():
                                                                      / np.abs(ref["f"][:S])))}))
 
     if "c4" in args.configs:  # Batch 1024 problems n=4096, full dense BFGS, fixed K=20 iterations
-        B, n, K = args.c4_batch, 4096, 20
+        B, n, K = args.c4_batch, 4096, args.c4_iterations
         d, b = quad(B, n, 10.0, 100.0)
         x = torch.zeros(B, n, dtype=torch.float64, device=dev)
         ws = NLO.bfgs_workspace(B, n, dev)
@@ -142,9 +143,11 @@ def main():
         algo = float((upd * 24 * n * n + (it > 0) * 8 * n * n).sum())
         # what the deferred form moves (n > 1024): one 8 n^2 read pass per update after the first, the first fold writes
         # 8 n^2 (H = a I was implicit), every later fold reads and writes 16 n^2
+        # (updates 1..J run on the implicit H = a I: no pass over H at all until the first fold)
         J = 8
-        folds = torch.div(it, J, rounding_mode="floor")
-        moved = float((torch.clamp(it - 1, min=0) * 8 * n * n + (folds > 0) * 8 * n * n
+        U = torch.clamp(it - 1, min=0)
+        folds = torch.div(U, J, rounding_mode="floor")
+        moved = float((torch.clamp(U - J, min=0) * 8 * n * n + (folds > 0) * 8 * n * n
                        + torch.clamp(folds - 1, min=0) * 16 * n * n).sum())
         Bc = 2 * cores  # the CPU oracle at n=4096 is O(n^2) per update too (update_form 1); as-written form 0 is O(n^3)
         oo = O.defaults(precision=1e-12, maxit=K - 1, exact_step=0)
@@ -298,6 +301,25 @@ def main():
                               "cpu_iterations_per_s": float(ref["iters"].sum()) / dt, "cpu": host, "cpu_sample": Bc,
                               "final_f_rel_err_max_vs_cpu": float(np.max(np.abs(out["f"][:Bc].cpu().numpy() - ref["f"])
                                                                          / np.abs(ref["f"])))}))
+
+    if "bigbfgs" in args.configs:  # dense BFGS beyond the register path: inverse Hessian in HBM, one workgroup per problem
+        for B, n, K in ((256, 8192, 20), (64, 16384, 12)):
+            d, b = quad(B, n, 10.0, 100.0)
+            x = torch.zeros(B, n, dtype=torch.float64, device=dev)
+            ws = NLO.bfgs_workspace(B, n, dev)
+
+            def run():
+                x.zero_()
+                return NLO.BFGS(NLO.DIAGQUAD, x, d, b, workspace_=ws, Precision=1e-12, MaxIteration=K - 1, ExactStep=0)
+            out, ms = timed(run, 1)
+            it = out["iters"].to(torch.int64)
+            U = torch.clamp(it - 1, min=0)
+            folds = torch.div(U, 8, rounding_mode="floor")
+            moved = float((torch.clamp(U - 8, min=0) * 8 * n * n + (folds > 0) * 8 * n * n
+                           + torch.clamp(folds - 1, min=0) * 16 * n * n).sum())
+            print(json.dumps({"config": f"dense BFGS (ExactStep=0) beyond the register path: quadratics n={n}, batch {B}, {K} iterations",
+                              "ms": ms, "iterations_per_s": float(it.sum()) / ms * 1e3, "iterations": int(it.sum()),
+                              "moved_GBps_model": moved / ms / 1e6, "inverse_hessian_bytes": B * n * n * 8}))
 
     if "c5" in args.configs:  # aug-Lagrangian wrapping L-BFGS, batch 8192 n=512, 8 equality constraints
         B, n, M, m = 8192, 512, 8, 10
