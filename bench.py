@@ -244,7 +244,7 @@ def main():
                            "algorithmic_bytes_per_launch": tl_bytes}
 
     # ---- CPU baseline: the oracle on a bounded sample of the same workload, all host cores
-    if args.cpu_sample != 0:
+    if args.cpu_sample != 0 and world == 1:  # reported at N = 1 only (the other ranks would wait at the barrier)
         import oracle_lib as O
         cores = host_cores()
         oo = O.defaults(precision=opts.precision, maxit=opts.max_iteration, memory=m)
