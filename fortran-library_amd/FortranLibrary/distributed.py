@@ -30,8 +30,9 @@ def gather_results(results, dst=0, group=None):
         dev = t.device
         if stage and t.is_cuda:
             t = t.cpu()
-        bufs = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
-        dist.gather(t, bufs, dst=dst, group=group)
+        # one [world, ...] buffer whose slices are the gather list: the ranks' blocks land in place, no concatenation pass
+        whole = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device) if rank == dst else None
+        dist.gather(t, list(whole.unbind(0)) if rank == dst else None, dst=dst, group=group)
         if rank == dst:
-            out[name] = torch.cat(bufs, dim=0).to(dev)
+            out[name] = whole.reshape((world * t.shape[0],) + tuple(t.shape[1:])).to(dev)
     return out
