@@ -12,7 +12,7 @@
 //           = column-major H' again, eps = rho adds rho s s^T in the epilogue.
 // U is never materialised: its 4 x 16 B-fragments (delta_kb - (rho y_k) s_b) are formed in registers,
 // so only one operand streams from HBM (coalesced 1 KiB rows -> LDS, double buffered).
-// Tile: 128 x 128 per workgroup (4 waves, 64 x 64 each = 16 accumulator tiles), BK = 16.
+// Tile: 128 x 128 per workgroup, BK = 16; WGM x WGN waves share it (default 2 x 4: 64 x 32 = 8 accumulator tiles each).
 // Fragment layouts of v_mfma_f64_16x16x4_f64: A lane l = A[l&15][l>>4], B lane l = B[l>>4][l&15],
 // C/D reg r of lane l = C[(l>>4) + 4 r][l&15].
 #include <hip/hip_runtime.h>
@@ -42,10 +42,22 @@ __global__ __launch_bounds__(256) void bfgs_rho_kernel(int n, const double *s_al
     for (int i = tid; i < n; i += 256) ry_all[(size_t)prob * n + i] = rho * y[i];
 }
 
-__global__ __launch_bounds__(256) void bfgs_gemm_kernel(int n, int ld, const double *in_all, double *out_all,
-                                                        size_t mat_stride, const double *ry_all, const double *s_all,
-                                                        const double *rho_all, int add_ss)
+// WGM x WGN waves per workgroup, each owning a (128/WGM) x (128/WGN) block of the tile = TM x TN accumulator tiles.
+// Measured on n = 4096 (profiles/r01/mfma_f64.txt): 2 x 2 waves (16 accumulator tiles each, one wave per SIMD) 37.7,
+// 4 x 4 (4 tiles, four waves per SIMD) 49.7, 4 x 2 61.7, 2 x 4 (8 tiles, two waves per SIMD) 65.4, 1 x 8 66.5 TFLOP/s
+// of the 78.6 TFLOP/s datasheet peak: two waves per SIMD with 8 accumulator tiles each keep the f64 MFMA pipe fed.
+#ifndef FL_GEMM_WGM
+#define FL_GEMM_WGM 2
+#define FL_GEMM_WGN 4
+#endif
+template <int WGM, int WGN>
+__global__ __launch_bounds__(WGM * WGN * 64) void bfgs_gemm_kernel(int n, int ld, const double *in_all, double *out_all,
+                                                                   size_t mat_stride, const double *ry_all,
+                                                                   const double *s_all, const double *rho_all, int add_ss)
 {
+    constexpr int NT = WGM * WGN * 64, TM = GBM / 16 / WGM, TN = GBN / 16 / WGN;
+    constexpr int PER = GBK * GBM / NT; // doubles each thread stages per k-block (8 with 256 threads, 2 with 1024)
+    static_assert(PER >= 2 && PER % 2 == 0, "staging in 16-byte pieces");
     __shared__ __attribute__((aligned(16))) double As[2][GBK][GBM];
     __shared__ double Rs[2][GBK];
     const int prob = blockIdx.y;
@@ -53,32 +65,33 @@ __global__ __launch_bounds__(256) void bfgs_gemm_kernel(int n, int ld, const dou
     const int ta = blockIdx.x / tiles_b, tb = blockIdx.x % tiles_b;
     const int a0 = ta * GBM, b0 = tb * GBN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wa = wave >> 1, wb = wave & 1;
+    const int wa = wave / WGN, wb = wave % WGN;
     const int lr = lane & 15, lq = lane >> 4;
     const double *in = in_all + (size_t)prob * mat_stride;
     double *out = out_all + (size_t)prob * mat_stride;
     const double *ry = ry_all + (size_t)prob * n, *s = s_all + (size_t)prob * n;
 
-    f64x4 acc[4][4];
+    f64x4 acc[TM][TN];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < TM; ++m)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[m][t] = f64x4{0.0, 0.0, 0.0, 0.0};
-    double sb[4];
-    int bcol[4];
+        for (int t = 0; t < TN; ++t) acc[m][t] = f64x4{0.0, 0.0, 0.0, 0.0};
+    double sb[TN];
+    int bcol[TN];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        bcol[t] = b0 + 64 * wb + 16 * t + lr;
+    for (int t = 0; t < TN; ++t) {
+        bcol[t] = b0 + 16 * TN * wb + 16 * t + lr;
         sb[t] = bcol[t] < n ? s[bcol[t]] : 0.0;
     }
-    // staging: thread t moves 8 doubles of the 16 x 128 tile: row kk = t>>4, columns 8*(t&15)..+7
-    const int skk = tid >> 4, sa = (tid & 15) * 8;
-    double2 st[4];
+    // staging: thread t moves PER doubles of the 16 x 128 tile: row kk = t / (128/PER), columns PER*(t % (128/PER))..
+    constexpr int TPR = GBM / PER; // threads per row
+    const int skk = tid / TPR, sa = (tid % TPR) * PER;
+    double2 st[PER / 2];
     auto gload = [&](int k0) {
         const int k = k0 + skk;
         const double *row = in + (size_t)k * ld + a0 + sa;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < PER / 2; ++u) {
             const int a = a0 + sa + 2 * u;
             st[u] = (k < n && a + 1 < ld) ? *reinterpret_cast<const double2 *>(row + 2 * u) : make_double2(0.0, 0.0);
             if (a >= n) st[u].x = 0.0;
@@ -87,7 +100,7 @@ __global__ __launch_bounds__(256) void bfgs_gemm_kernel(int n, int ld, const dou
     };
     auto lstore = [&](int buf, int k0) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) *reinterpret_cast<double2 *>(&As[buf][skk][sa + 2 * u]) = st[u];
+        for (int u = 0; u < PER / 2; ++u) *reinterpret_cast<double2 *>(&As[buf][skk][sa + 2 * u]) = st[u];
         if (tid < GBK) Rs[buf][tid] = (k0 + tid < n) ? ry[k0 + tid] : 0.0;
     };
     gload(0);
@@ -102,15 +115,15 @@ __global__ __launch_bounds__(256) void bfgs_gemm_kernel(int n, int ld, const dou
             const int kk = 4 * ks + lq;
             const int k = k0 + kk;
             const double ryk = Rs[buf][kk];
-            double af[4], bf[4];
+            double af[TM], bf[TN];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) af[m] = As[buf][kk][64 * wa + 16 * m + lr];
+            for (int m = 0; m < TM; ++m) af[m] = As[buf][kk][16 * TM * wa + 16 * m + lr];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) bf[t] = ((k == bcol[t]) ? 1.0 : 0.0) - ryk * sb[t]; // U[k][b]
+            for (int t = 0; t < TN; ++t) bf[t] = ((k == bcol[t]) ? 1.0 : 0.0) - ryk * sb[t]; // U[k][b]
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < TM; ++m)
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < TN; ++t)
                     acc[m][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[t], acc[m][t], 0, 0, 0);
         }
         if (more) lstore(buf ^ 1, k0 + GBK);
@@ -119,14 +132,14 @@ __global__ __launch_bounds__(256) void bfgs_gemm_kernel(int n, int ld, const dou
     }
     const double eps = add_ss ? rho_all[prob] : 0.0;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < TM; ++m) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int a = a0 + 64 * wa + 16 * m + lq + 4 * r;
+            const int a = a0 + 16 * TM * wa + 16 * m + lq + 4 * r;
             if (a < n) {
                 const double esa = eps * s[a];
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < TN; ++t)
                     if (bcol[t] < n) out[(size_t)a * ld + bcol[t]] = acc[m][t][r] + esa * sb[t];
             }
         }
@@ -167,8 +180,10 @@ int fl_bfgs_update_gemm_batched(int batch, int n, double *H_dev, const double *s
         double *H = H_dev + p0 * mat;
         const double *s = s_dev + p0 * (size_t)n, *y = y_dev + p0 * (size_t)n;
         hipLaunchKernelGGL(fl::bfgs_rho_kernel, dim3(c), dim3(256), 0, st, n, s, y, rho, ry);
-        hipLaunchKernelGGL(fl::bfgs_gemm_kernel, dim3(tiles, c), dim3(256), 0, st, n, (int)ld, H, T, mat, ry, s, rho, 0);
-        hipLaunchKernelGGL(fl::bfgs_gemm_kernel, dim3(tiles, c), dim3(256), 0, st, n, (int)ld, T, H, mat, ry, s, rho, 1);
+        hipLaunchKernelGGL((fl::bfgs_gemm_kernel<FL_GEMM_WGM, FL_GEMM_WGN>), dim3(tiles, c), dim3(FL_GEMM_WGM * FL_GEMM_WGN * 64), 0, st, n, (int)ld, H, T,
+                           mat, ry, s, rho, 0);
+        hipLaunchKernelGGL((fl::bfgs_gemm_kernel<FL_GEMM_WGM, FL_GEMM_WGN>), dim3(tiles, c), dim3(FL_GEMM_WGM * FL_GEMM_WGN * 64), 0, st, n, (int)ld, T, H,
+                           mat, ry, s, rho, 1);
     }
     return hipGetLastError() == hipSuccess ? FL_OK : FL_ERR_NO_DEVICE;
 }
