@@ -126,6 +126,15 @@ def test_legacy_entry_points_beyond_the_register_path_n5001():
                         threads=T, ept=E)
     assert np.array_equal(x, ref["x"][0])
     assert cnt["f"] == ref["nf"][0] and cnt["fd"] == ref["ng"][0]
+    for k in cnt:
+        cnt[k] = 0
+    x = x0.copy()
+    vals, refs = _common(maxit=12, precision=1e-9, strong=False)
+    FL.__nonlinearoptimization_MOD_steepestdescent(f, fd, x.ctypes.data_as(dp), C.byref(dim), None, *refs)
+    ref = O.solve_batch(O.SD, O.ROSENBROCK, x0, opts=O.defaults(maxit=12, precision=1e-9, strong=0), sum_mode=O.TREE,
+                        threads=T, ept=E)
+    assert np.array_equal(x, ref["x"][0])
+    assert cnt["f"] == ref["nf"][0] and cnt["fd"] == ref["ng"][0]
 
 
 def test_legacy_test_cpp_sequence_quartic_dim10():
