@@ -219,6 +219,70 @@ template <int OBJ, int METHOD> struct BigSolver {
         ggo = uni(r[3]);
         if constexpr (OBJ == FL_OBJ_ROSENBROCK) __syncthreads(); // all neighbour reads done before x moves again
     }
+    // a trial in ONE pass: x = x0 + at p formed, stored and evaluated together (Rosenbrock's neighbours are formed
+    // from x0, p the same way -- bitwise the neighbour thread's x -- so no barrier is needed)
+    __device__ __forceinline__ void move_evaluate(double at, double &f, double &gp, double &ggo)
+    {
+        if constexpr (OBJ == FL_OBJ_ROSENBROCK) __syncthreads(); // x0 / p rows of the neighbours are complete
+        double r[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int c = 0; c < nslot; ++c) {
+            const int e = e_of(c);
+            double oa, ob, pa, pb, ga, gb, ta, tb, ua = 0.0, ub = 0.0;
+            ldw(x0, e, oa, ob);
+            ldw(p, e, pa, pb);
+            const double xa = oa + at * pa, xb = ob + at * pb;
+            stu(x, e, xa, xb);
+            if constexpr (OBJ == FL_OBJ_QUARTIC) {
+                const double a3 = xa * xa * xa, b3 = xb * xb * xb;
+                ta = a3 * xa;
+                tb = b3 * xb;
+                ga = 4.0 * a3;
+                gb = 4.0 * b3;
+            } else if constexpr (OBJ == FL_OBJ_DIAGQUAD) {
+                double da, db, ba, bbv;
+                ldu(dd, e, da, db);
+                ldu(bb, e, ba, bbv);
+                const double dxa = da * xa, dxb = db * xb;
+                ta = dxa * xa;
+                tb = dxb * xb;
+                ua = ba * xa;
+                ub = bbv * xb;
+                ga = dxa - ba;
+                gb = dxb - bbv;
+            } else if constexpr (OBJ == FL_OBJ_ROSENBROCK) {
+                const double xl = (e >= 1 && e - 1 < n) ? x0[e - 1] + at * p[e - 1] : 0.0;
+                const double xr = (e + 2 < n) ? x0[e + 2] + at * p[e + 2] : 0.0;
+                const double ul = xa - xl * xl, um = xb - xa * xa, ur = xr - xb * xb;
+                const double va = 1.0 - xa, vb = 1.0 - xb;
+                const double A_a = (e >= 1) ? 200.0 * ul : 0.0;
+                const double A_b = 200.0 * um;
+                ta = tb = ga = gb = 0.0;
+                if (e <= n - 2) {
+                    ta = 100.0 * (um * um) + va * va;
+                    ga = A_a - 400.0 * xa * um - 2.0 * va;
+                } else if (e == n - 1) {
+                    ga = A_a;
+                }
+                if (e + 1 <= n - 2) {
+                    tb = 100.0 * (ur * ur) + vb * vb;
+                    gb = A_b - 400.0 * xb * ur - 2.0 * vb;
+                } else if (e + 1 == n - 1) {
+                    gb = A_b;
+                }
+            } else {
+                ta = tb = ga = gb = 0.0;
+            }
+            stw(g, e, ga, gb);
+            acc2(r[0], c, ta, tb);
+            if constexpr (OBJ == FL_OBJ_DIAGQUAD) acc2(r[1], c, ua, ub);
+            acc2(r[2], c, ga * pa, gb * pb);
+            acc2(r[3], c, ga * ga, gb * gb);
+        }
+        R.run(r);
+        f = uni(Objective<OBJ, 1, 2>::combine(r[0], r[1]));
+        gp = uni(r[2]);
+        ggo = uni(r[3]);
+    }
     // reverse communication: the caller's gradient [n] -> g, with g.p and g.g
     __device__ __forceinline__ void take_gradient(const double *g_user, double &gp, double &ggo)
     {

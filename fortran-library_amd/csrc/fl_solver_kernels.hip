@@ -65,8 +65,8 @@ template <int OBJ, int METHOD> __global__ __launch_bounds__(1024) void fl_big_so
     double fv = 0.0, pv = 0.0, gg = 0.0;
     while (rq) {
         if (!(rq & FL_REQ_SAME)) {
-            if (!(rq & FL_REQ_NOMOVE)) s.move(s.request_point());
-            s.evaluate(fv, pv, gg);
+            if (rq & FL_REQ_NOMOVE) s.evaluate(fv, pv, gg);
+            else s.move_evaluate(s.request_point(), fv, pv, gg); // the trial point is formed and evaluated in one pass
         }
         rq = s.advance(fv, pv, gg);
     }
