@@ -54,7 +54,7 @@ class FLError(RuntimeError):
 def _check(rc, what):
     if rc != OK:
         names = {-1: "FL_ERR_INVALID_ARGUMENT", -2: "FL_ERR_UNSUPPORTED_SIZE", -3: "FL_ERR_WORKSPACE",
-                 -4: "FL_ERR_NO_DEVICE"}
+                 -4: "FL_ERR_NO_DEVICE", -5: "FL_ERR_LAUNCH"}
         raise FLError(f"{what} failed: {names.get(rc, rc)}")
 
 

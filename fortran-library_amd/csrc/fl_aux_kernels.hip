@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/fl_nlopt.h"
+#include "fl_host.hpp"
 #include "fl_reduce.hpp"
 
 namespace fl {
@@ -189,7 +190,7 @@ int fl_synth_uniform(uint64_t seed, int batch, int n, double lo, double hi, doub
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FL_ERR_NO_DEVICE;
     hipLaunchKernelGGL(fl::synth_uniform_kernel, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(stream), seed,
                        batch, n, lo, hi, out_dev);
-    return hipGetLastError() == hipSuccess ? FL_OK : FL_ERR_NO_DEVICE;
+    return fl::launch_status();
 }
 
 int fl_synth_diag_spectrum(uint64_t seed, int batch, int n, double kappa_lo, double kappa_hi, double *d_dev,
@@ -201,7 +202,7 @@ int fl_synth_diag_spectrum(uint64_t seed, int batch, int n, double kappa_lo, dou
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FL_ERR_NO_DEVICE;
     hipLaunchKernelGGL(fl::synth_spectrum_kernel, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(stream), seed,
                        batch, n, log(kappa_lo), log(kappa_hi), d_dev);
-    return hipGetLastError() == hipSuccess ? FL_OK : FL_ERR_NO_DEVICE;
+    return fl::launch_status();
 }
 
 int fl_lbfgs_two_loop_batched(int batch, int n, int memory, int recent, const double *hist_dev,
@@ -210,7 +211,8 @@ int fl_lbfgs_two_loop_batched(int batch, int n, int memory, int recent, const do
     if (!hist_dev || !rho_dev || !g_dev || !p_dev || batch <= 0 || n <= 0) return FL_ERR_INVALID_ARGUMENT;
     if (memory < 1 || memory > FL_MAX_MEMORY || recent < 0 || recent >= memory) return FL_ERR_INVALID_ARGUMENT;
     int threads = 0, ept = 0;
-    if (fl_reduction_geometry(n, &threads, &ept) != FL_OK) return FL_ERR_UNSUPPORTED_SIZE;
+    // the stand-alone recursion exists for the register geometries (n <= 4096) only
+    if (n > 4096 || fl_reduction_geometry(n, &threads, &ept) != FL_OK) return FL_ERR_UNSUPPORTED_SIZE;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FL_ERR_NO_DEVICE;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -226,9 +228,10 @@ int fl_lbfgs_two_loop_batched(int batch, int n, int memory, int recent, const do
     else if (nw == 8 && ept == 2) FL_TL(8, 2);
     else if (nw == 1 && ept == 16) FL_TL(1, 16);
     else if (nw == 4 && ept == 8) FL_TL(4, 8);
-    else FL_TL(8, 8);
+    else if (nw == 8 && ept == 8) FL_TL(8, 8);
+    else return FL_ERR_UNSUPPORTED_SIZE;
 #undef FL_TL
-    return hipGetLastError() == hipSuccess ? FL_OK : FL_ERR_NO_DEVICE;
+    return fl::launch_status();
 }
 
 } // extern "C"

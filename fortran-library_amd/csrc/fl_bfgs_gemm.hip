@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/fl_nlopt.h"
+#include "fl_host.hpp"
 #include "fl_reduce.hpp"
 
 namespace fl {
@@ -185,7 +186,7 @@ int fl_bfgs_update_gemm_batched(int batch, int n, double *H_dev, const double *s
         hipLaunchKernelGGL((fl::bfgs_gemm_kernel<FL_GEMM_WGM, FL_GEMM_WGN>), dim3(tiles, c), dim3(FL_GEMM_WGM * FL_GEMM_WGN * 64), 0, st, n, (int)ld, T, H,
                            mat, ry, s, rho, 1);
     }
-    return hipGetLastError() == hipSuccess ? FL_OK : FL_ERR_NO_DEVICE;
+    return fl::launch_status();
 }
 
 } // extern "C"

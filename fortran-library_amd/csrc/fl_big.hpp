@@ -33,6 +33,7 @@ template <int OBJ, int METHOD> struct BigSolver {
     static constexpr int L_STAGE = L_ALPHA + FL_MAX_MEMORY;
     static constexpr int LDS_TOTAL = L_STAGE + (METHOD == FL_SOLVER_BFGS ? 2 * BF_DEFER * BF_FOLD_COLS + 4 : 0);
     static constexpr int RCI_SCALARS = 48;
+    static constexpr int UNI_LEVEL = (METHOD == FL_SOLVER_BFGS) ? 2 : FL_UNI_LEVEL; // 128 VGPRs per wave: BFGS pins the search to SGPRs
 
     const SolveArgs &A;
     double *lds;
@@ -312,7 +313,7 @@ template <int OBJ, int METHOD> struct BigSolver {
         } else {
             gg = gg_new;
             rq = __builtin_amdgcn_readfirstlane(ls.step(fv, pv));
-            ls.uniformize();
+            ls.template uniformize<UNI_LEVEL>();
             if (rq == 0) rq = after_linesearch();
         }
         pending = rq;
@@ -367,7 +368,7 @@ template <int OBJ, int METHOD> struct BigSolver {
         const int strong = (METHOD == FL_SOLVER_CG && A.cg_method == FL_CG_PR) ? 1 : A.strong;
         phase = PH_LS;
         const int rq = __builtin_amdgcn_readfirstlane(ls.begin(strong, fused, A.c1, A.c2, A.incr, a, fnew, phid));
-        ls.uniformize();
+        ls.template uniformize<UNI_LEVEL>();
         return rq;
     }
     __device__ __forceinline__ int after_init(double f, double gg0)
@@ -609,37 +610,59 @@ template <int OBJ, int METHOD> struct BigSolver {
             h_ident = 1;
             a_id = a;
         }
-        double q[2 * BF_MAX_SLOTS], w[2 * BF_MAX_SLOTS];
+        // q = H_cur y and w = H_cur g are kept as ROWS like everything else on this path (q in the row it will occupy
+        // as q_l of the new pending update, w in p's row, which is free until the direction is rebuilt below): with
+        // 1024 threads a wave has 128 VGPRs, and 8 slots of q and w in registers (64 of them) next to the column
+        // loads spilled 240-310 VGPRs (1200 in the reverse-communication kernel).
+        double *Sn = def_row(2 * ndef), *Qn = def_row(2 * ndef + 1), *wrow = p;
         if (h_ident) {
-#pragma unroll
-            for (int c = 0; c < BF_MAX_SLOTS; ++c) {
-                if (c < nslot) {
-                    const int e = e_of(c);
-                    double ya, yb, ga, gb;
-                    ldw(yrow, e, ya, yb);
-                    ldw(g, e, ga, gb);
-                    q[2 * c] = a_id * ya;
-                    q[2 * c + 1] = a_id * yb;
-                    w[2 * c] = a_id * ga;
-                    w[2 * c + 1] = a_id * gb;
-                }
+            for (int c = 0; c < nslot; ++c) {
+                const int e = e_of(c);
+                double ya, yb, ga, gb;
+                ldw(yrow, e, ya, yb);
+                ldw(g, e, ga, gb);
+                stw(Qn, e, a_id * ya, a_id * yb);
+                stw(wrow, e, a_id * ga, a_id * gb);
             }
         } else {
             __syncthreads(); // y row complete
+            // one read pass over H: q = H y, w = H g.  Two slots of rows at a time (every column is read in
+            // nslot / 2 pieces of 2 KiB per wave), four columns in flight; thread i sums over j in order.
+            constexpr int SG = 2, JU = 4;
+            for (int c0 = 0; c0 < nslot; c0 += SG) {
+                double q[2 * SG], w[2 * SG];
 #pragma unroll
-            for (int k = 0; k < 2 * BF_MAX_SLOTS; ++k) q[k] = w[k] = 0.0;
-            for (int j = 0; j < n; ++j) { // one read pass over H: q = H y, w = H g
-                const double yj = yrow[j], gj = g[j];
-                const double *col = H + (size_t)j * npad;
+                for (int k = 0; k < 2 * SG; ++k) q[k] = w[k] = 0.0;
+                for (int j = 0; j < n; j += JU) {
+                    double h[JU][2 * SG];
 #pragma unroll
-                for (int c = 0; c < BF_MAX_SLOTS; ++c) {
-                    if (c < nslot) {
-                        double ha, hb;
-                        ldw(col, e_of(c), ha, hb);
-                        q[2 * c] = q[2 * c] + ha * yj;
-                        q[2 * c + 1] = q[2 * c + 1] + hb * yj;
-                        w[2 * c] = w[2 * c] + ha * gj;
-                        w[2 * c + 1] = w[2 * c + 1] + hb * gj;
+                    for (int u = 0; u < JU; ++u) {
+                        const double *col = H + (size_t)(j + u < n ? j + u : j) * npad;
+#pragma unroll
+                        for (int cc = 0; cc < SG; ++cc)
+                            if (c0 + cc < nslot) ldw(col, e_of(c0 + cc), h[u][2 * cc], h[u][2 * cc + 1]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < JU; ++u) {
+                        if (j + u < n) {
+                            const double yj = yrow[j + u], gj = g[j + u];
+#pragma unroll
+                            for (int cc = 0; cc < SG; ++cc) {
+                                if (c0 + cc < nslot) {
+                                    q[2 * cc] = q[2 * cc] + h[u][2 * cc] * yj;
+                                    q[2 * cc + 1] = q[2 * cc + 1] + h[u][2 * cc + 1] * yj;
+                                    w[2 * cc] = w[2 * cc] + h[u][2 * cc] * gj;
+                                    w[2 * cc + 1] = w[2 * cc + 1] + h[u][2 * cc + 1] * gj;
+                                }
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int cc = 0; cc < SG; ++cc) {
+                    if (c0 + cc < nslot) {
+                        stw(Qn, e_of(c0 + cc), q[2 * cc], q[2 * cc + 1]);
+                        stw(wrow, e_of(c0 + cc), w[2 * cc], w[2 * cc + 1]);
                     }
                 }
             }
@@ -661,57 +684,49 @@ template <int OBJ, int METHOD> struct BigSolver {
             }
             R.run(r);
             const double rl = drho[l], cl = dcs[l];
-#pragma unroll
-            for (int c = 0; c < BF_MAX_SLOTS; ++c) {
-                if (c < nslot) {
-                    const int e = e_of(c);
-                    double sa, sb, qa, qb;
-                    ldw(S, e, sa, sb);
-                    ldw(Q, e, qa, qb);
-                    const double rqa = rl * qa, rqb = rl * qb, rsa = rl * sa, rsb = rl * sb, cca = cl * sa, ccb = cl * sb;
-                    q[2 * c] = q[2 * c] - rqa * r[0] - rsa * r[1] + cca * r[0];
-                    q[2 * c + 1] = q[2 * c + 1] - rqb * r[0] - rsb * r[1] + ccb * r[0];
-                    w[2 * c] = w[2 * c] - rqa * r[2] - rsa * r[3] + cca * r[2];
-                    w[2 * c + 1] = w[2 * c + 1] - rqb * r[2] - rsb * r[3] + ccb * r[2];
-                }
+            for (int c = 0; c < nslot; ++c) {
+                const int e = e_of(c);
+                double sa, sb, qa, qb, q0, q1, w0, w1;
+                ldw(S, e, sa, sb);
+                ldw(Q, e, qa, qb);
+                ldw(Qn, e, q0, q1);
+                ldw(wrow, e, w0, w1);
+                const double rqa = rl * qa, rqb = rl * qb, rsa = rl * sa, rsb = rl * sb, cca = cl * sa, ccb = cl * sb;
+                stw(Qn, e, q0 - rqa * r[0] - rsa * r[1] + cca * r[0], q1 - rqb * r[0] - rsb * r[1] + ccb * r[0]);
+                stw(wrow, e, w0 - rqa * r[2] - rsa * r[3] + cca * r[2], w1 - rqb * r[2] - rsb * r[3] + ccb * r[2]);
             }
         }
         double r3[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-        for (int c = 0; c < BF_MAX_SLOTS; ++c) {
-            if (c < nslot) {
-                const int e = e_of(c);
-                double ya, yb, ga, gb, xa, xb, oa, ob;
-                ldw(yrow, e, ya, yb);
-                ldw(g, e, ga, gb);
-                ldu(x, e, xa, xb);
-                ldw(x0, e, oa, ob);
-                acc2(r3[0], c, ya * q[2 * c], yb * q[2 * c + 1]);
-                acc2(r3[1], c, (xa - oa) * ga, (xb - ob) * gb);
-                acc2(r3[2], c, q[2 * c] * ga, q[2 * c + 1] * gb);
-            }
+        for (int c = 0; c < nslot; ++c) {
+            const int e = e_of(c);
+            double ya, yb, ga, gb, xa, xb, oa, ob, q0, q1;
+            ldw(yrow, e, ya, yb);
+            ldw(g, e, ga, gb);
+            ldu(x, e, xa, xb);
+            ldw(x0, e, oa, ob);
+            ldw(Qn, e, q0, q1);
+            acc2(r3[0], c, ya * q0, yb * q1);
+            acc2(r3[1], c, (xa - oa) * ga, (xb - ob) * gb);
+            acc2(r3[2], c, q0 * ga, q1 * gb);
         }
         R.run(r3);
         const double cs = uni(rho * rho * r3[0] + rho);
         double r4[2] = {0.0, 0.0};
-        double *Sn = def_row(2 * ndef), *Qn = def_row(2 * ndef + 1);
-#pragma unroll
-        for (int c = 0; c < BF_MAX_SLOTS; ++c) {
-            if (c < nslot) {
-                const int e = e_of(c);
-                double ga, gb, xa, xb, oa, ob;
-                ldw(g, e, ga, gb);
-                ldu(x, e, xa, xb);
-                ldw(x0, e, oa, ob);
-                const double sa = xa - oa, sb = xb - ob;
-                const double pa = -(w[2 * c] - (rho * q[2 * c]) * r3[1] - (rho * sa) * r3[2] + (cs * sa) * r3[1]);
-                const double pb = -(w[2 * c + 1] - (rho * q[2 * c + 1]) * r3[1] - (rho * sb) * r3[2] + (cs * sb) * r3[1]);
-                stw(p, e, pa, pb);
-                stw(Sn, e, sa, sb);
-                stw(Qn, e, q[2 * c], q[2 * c + 1]);
-                acc2(r4[0], c, ga * pa, gb * pb);
-                acc2(r4[1], c, pa * pa, pb * pb);
-            }
+        for (int c = 0; c < nslot; ++c) {
+            const int e = e_of(c);
+            double ga, gb, xa, xb, oa, ob, q0, q1, w0, w1;
+            ldw(g, e, ga, gb);
+            ldu(x, e, xa, xb);
+            ldw(x0, e, oa, ob);
+            ldw(Qn, e, q0, q1);
+            ldw(wrow, e, w0, w1);
+            const double sa = xa - oa, sb = xb - ob;
+            const double pa = -(w0 - (rho * q0) * r3[1] - (rho * sa) * r3[2] + (cs * sa) * r3[1]);
+            const double pb = -(w1 - (rho * q1) * r3[1] - (rho * sb) * r3[2] + (cs * sb) * r3[1]);
+            stw(p, e, pa, pb);
+            stw(Sn, e, sa, sb);
+            acc2(r4[0], c, ga * pa, gb * pb);
+            acc2(r4[1], c, pa * pa, pb * pb);
         }
         if (tid == 0) {
             drho[ndef] = rho;
@@ -724,24 +739,24 @@ template <int OBJ, int METHOD> struct BigSolver {
         pp = r4[1];
         a = 1.0;
     }
+    // H <- H with the pending updates applied in order: one ELEMENT row per thread and sweep (the row factors of
+    // the eight pending updates for one row are 24 doubles; for a 16-byte pair they were 96 VGPRs of the 128)
     __device__ __forceinline__ void bfgs_fold()
     {
         constexpr int J = BF_DEFER, CB = BF_FOLD_COLS;
         double *H = hist, *stage = lds + L_STAGE;
         const double *drho = lds + L_RHO, *dcs = drho + J;
         __syncthreads();
-        for (int c = 0; c < nslot; ++c) {
-            const int e = e_of(c);
-            double rq[J][2], rs[J][2], cf[J][2];
+        for (int c2 = 0; c2 < 2 * nslot; ++c2) {
+            const int e = e_of(c2 >> 1) + (c2 & 1);
+            double rq[J], rs[J], cf[J];
 #pragma unroll
             for (int l = 0; l < J; ++l) {
-                double sa, sb, qa, qb;
-                ldw(def_row(2 * l), e, sa, sb);
-                ldw(def_row(2 * l + 1), e, qa, qb);
+                const double sv = def_row(2 * l)[e], qv = def_row(2 * l + 1)[e];
                 const double rl = drho[l], cl = dcs[l];
-                rq[l][0] = rl * qa; rq[l][1] = rl * qb;
-                rs[l][0] = rl * sa; rs[l][1] = rl * sb;
-                cf[l][0] = cl * sa; cf[l][1] = cl * sb;
+                rq[l] = rl * qv;
+                rs[l] = rl * sv;
+                cf[l] = cl * sv;
             }
             for (int jb = 0; jb < n; jb += CB) {
                 __syncthreads();
@@ -753,21 +768,14 @@ template <int OBJ, int METHOD> struct BigSolver {
                 const int jend = (n - jb < CB) ? n - jb : CB;
                 for (int jj = 0; jj < jend; ++jj) {
                     const int j = jb + jj;
-                    double *hp = H + (size_t)j * npad;
-                    double ha, hb;
-                    if (h_ident) {
-                        ha = (e == j) ? a_id : 0.0;
-                        hb = (e + 1 == j) ? a_id : 0.0;
-                    } else {
-                        ldw(hp, e, ha, hb);
-                    }
+                    double *hp = H + (size_t)j * npad + e;
+                    double ha = h_ident ? ((e == j) ? a_id : 0.0) : *hp;
 #pragma unroll
                     for (int l = 0; l < J; ++l) {
                         const double sj = stage[(2 * l) * CB + jj], qj = stage[(2 * l + 1) * CB + jj];
-                        ha = ha - rq[l][0] * sj - rs[l][0] * qj + cf[l][0] * sj;
-                        hb = hb - rq[l][1] * sj - rs[l][1] * qj + cf[l][1] * sj;
+                        ha = ha - rq[l] * sj - rs[l] * qj + cf[l] * sj;
                     }
-                    stw(hp, e, ha, hb);
+                    *hp = ha;
                 }
             }
         }

@@ -27,9 +27,10 @@ template <int NW, int EPT> struct Dense {
 #define FL_DENSE_BW 8 // measured: Newton n=256 x 4096: 143 k it/s (2), 254 k (4), 387 k (8); column-at-a-time 79 k
 #endif
     // n <= 128 (EPT = 2): 4 -- the wider block costs the small BFGS kernels 70 VGPRs (4 -> 2 waves/SIMD) for nothing
-    static constexpr int BW = (EPT <= 2 && FL_DENSE_BW > 4) ? 4 : FL_DENSE_BW, KT = (NPAD / BW < 256) ? NPAD / BW : 256; // BW*KT <= NPAD doubles of LDS
+    // 512 threads x 8 elements (2 waves / SIMD, 256 VGPRs): 6 -- with 8 the Newton kernels spilled 9-200 VGPRs
+    static constexpr int BW = (EPT <= 2 && FL_DENSE_BW > 4) ? 4 : ((NW >= 8 && EPT >= 8 && FL_DENSE_BW > 6) ? 6 : FL_DENSE_BW), KT = (NPAD / BW < 256) ? NPAD / BW : 256; // BW*KT <= NPAD doubles of LDS
     static constexpr int UNR = BW; // columns of W^T W per sweep
-    __device__ static int cholesky(double *A, int n, double *rowbuf, double *slot)
+    __device__ __forceinline__ static int cholesky(double *A, int n, double *rowbuf, double *slot)
     {
         int info = 0;
         for (int j0 = 0; j0 < n && info == 0; j0 += BW) {
@@ -41,7 +42,7 @@ template <int NW, int EPT> struct Dense {
             for (int kt = 0; kt < j0; kt += KT) {
                 const int kn = (j0 - kt < KT) ? j0 - kt : KT;
                 __syncthreads();
-                for (int i = threadIdx.x; i < kn * BW; i += G::T) { // rowbuf[u*KT + kk] = L(j0+u, kt+kk)
+                for (int i = G::tid(); i < kn * BW; i += G::T) { // rowbuf[u*KT + kk] = L(j0+u, kt+kk)
                     const int kk = i / BW, u = i - kk * BW;
                     rowbuf[u * KT + kk] = (u < bw) ? A[(size_t)(kt + kk) * NPAD + j0 + u] : 0.0;
                 }
@@ -104,7 +105,7 @@ template <int NW, int EPT> struct Dense {
 
     // solve L L^T x = b, b in registers (in/out).  Forward: column-oriented axpy (dtrsv 'L','N');
     // backward: x_j = (z_j - sum_{i>j} L(i,j) x_i) / L(j,j) with the sum reduced in the kernels' order.
-    __device__ static void solve(const double *L, int n, double (&b)[EPT], Reducer<NW> &R, double *slot)
+    __device__ __forceinline__ static void solve(const double *L, int n, double (&b)[EPT], Reducer<NW> &R, double *slot)
     {
         for (int j = 0; j < n; ++j) {
             double c[EPT];
@@ -146,7 +147,7 @@ template <int NW, int EPT> struct Dense {
     // W = inverse of the lower factor, stored by ROWS: Wt[j*NPAD + c] = W(j,c).
     // W(j,:) = (e_j - sum_{k<j} L(j,k) W(k,:)) / L(j,j): each thread owns columns c, sums over k in order.
     // BW rows at a time (every earlier row of W is read once per block; same order of operations per element).
-    __device__ static void inverse_factor(const double *L, double *Wt, int n, double *rowbuf)
+    __device__ __forceinline__ static void inverse_factor(const double *L, double *Wt, int n, double *rowbuf)
     {
         for (int j0 = 0; j0 < n; j0 += BW) {
             const int bw = (n - j0 < BW) ? n - j0 : BW;
@@ -158,7 +159,7 @@ template <int NW, int EPT> struct Dense {
             for (int kt = 0; kt < j0; kt += KT) {
                 const int kn = (j0 - kt < KT) ? j0 - kt : KT;
                 __syncthreads();
-                for (int i = threadIdx.x; i < kn * BW; i += G::T) { // rowbuf[u*KT + kk] = L(j0+u, kt+kk)
+                for (int i = G::tid(); i < kn * BW; i += G::T) { // rowbuf[u*KT + kk] = L(j0+u, kt+kk)
                     const int kk = i / BW, u = i - kk * BW;
                     rowbuf[u * KT + kk] = (u < bw) ? L[(size_t)(kt + kk) * NPAD + j0 + u] : 0.0;
                 }
@@ -182,7 +183,7 @@ template <int NW, int EPT> struct Dense {
             }
             // inside the block: L(j0+u, j0+u') for u' <= u (BW x BW values)
             __syncthreads();
-            for (int i = threadIdx.x; i < BW * BW; i += G::T) {
+            for (int i = G::tid(); i < BW * BW; i += G::T) {
                 const int u = i / BW, u2 = i - u * BW;
                 rowbuf[i] = (u < bw && u2 <= u) ? L[(size_t)(j0 + u2) * NPAD + j0 + u] : 0.0;
             }
@@ -209,7 +210,7 @@ template <int NW, int EPT> struct Dense {
     }
 
     // Ainv = W^T W (full symmetric matrix, column-major): Ainv(a,b) = sum_k W(k,a) W(k,b), k in order
-    __device__ static void wtw(const double *Wt, double *Ainv, int n, double *rowbuf)
+    __device__ __forceinline__ static void wtw(const double *Wt, double *Ainv, int n, double *rowbuf)
     {
         for (int b0 = 0; b0 < n; b0 += UNR) {
             double acc[UNR][EPT];

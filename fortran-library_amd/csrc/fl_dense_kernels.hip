@@ -4,6 +4,7 @@
 // One workgroup per matrix, the device routines of fl_dense.hpp (the same ones NewtonRaphson and the exact-
 // Hessian refresh of BFGS use inside the fused solver).
 #include "fl_device.hpp"
+#include "fl_host.hpp"
 
 namespace fl {
 
@@ -173,31 +174,36 @@ extern "C" {
         else if (nw == 2 && ept == 4) hipLaunchKernelGGL((fl::KERNEL<2, 4>), dim3(batch), dim3(128), 0, st, __VA_ARGS__); \
         else if (nw == 2 && ept == 8) hipLaunchKernelGGL((fl::KERNEL<2, 8>), dim3(batch), dim3(128), 0, st, __VA_ARGS__); \
         else if (nw == 4 && ept == 8) hipLaunchKernelGGL((fl::KERNEL<4, 8>), dim3(batch), dim3(256), 0, st, __VA_ARGS__); \
-        else hipLaunchKernelGGL((fl::KERNEL<8, 8>), dim3(batch), dim3(512), 0, st, __VA_ARGS__);                   \
+        else if (nw == 8 && ept == 8) hipLaunchKernelGGL((fl::KERNEL<8, 8>), dim3(batch), dim3(512), 0, st, __VA_ARGS__); \
+        else return FL_ERR_UNSUPPORTED_SIZE; /* a geometry none of the dense kernels is built for */                 \
     } while (0)
 
 int fl_dposv_batched(int batch, int n, double *A_dev, double *b_dev, int32_t *info_dev, void *stream)
 {
     if (!A_dev || !b_dev || batch <= 0 || n <= 0) return FL_ERR_INVALID_ARGUMENT;
     int threads = 0, ept = 0;
-    if (fl_reduction_geometry(n, &threads, &ept) != FL_OK) return FL_ERR_UNSUPPORTED_SIZE;
+    // one workgroup per matrix with its rows in registers: the register geometries only (beyond n = 4096
+    // fl_reduction_geometry answers with the vectors-in-HBM layout, which these kernels do not have)
+    if (n > 4096 || fl_reduction_geometry(n, &threads, &ept) != FL_OK) return FL_ERR_UNSUPPORTED_SIZE;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FL_ERR_NO_DEVICE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     FL_GEO_DISPATCH(dposv_kernel, n, A_dev, b_dev, info_dev);
-    return hipGetLastError() == hipSuccess ? FL_OK : FL_ERR_NO_DEVICE;
+    return fl::launch_status();
 }
 
 int fl_dpotri_batched(int batch, int n, double *A_dev, double *work_dev, int32_t *info_dev, void *stream)
 {
     if (!A_dev || !work_dev || batch <= 0 || n <= 0) return FL_ERR_INVALID_ARGUMENT;
     int threads = 0, ept = 0;
-    if (fl_reduction_geometry(n, &threads, &ept) != FL_OK) return FL_ERR_UNSUPPORTED_SIZE;
+    // one workgroup per matrix with its rows in registers: the register geometries only (beyond n = 4096
+    // fl_reduction_geometry answers with the vectors-in-HBM layout, which these kernels do not have)
+    if (n > 4096 || fl_reduction_geometry(n, &threads, &ept) != FL_OK) return FL_ERR_UNSUPPORTED_SIZE;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FL_ERR_NO_DEVICE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     FL_GEO_DISPATCH(dpotri_kernel, n, A_dev, work_dev, info_dev);
-    return hipGetLastError() == hipSuccess ? FL_OK : FL_ERR_NO_DEVICE;
+    return fl::launch_status();
 }
 
 int fl_dsysv_batched(int batch, int n, double *A_dev, double *b_dev, int32_t *info_dev, void *stream)
@@ -209,7 +215,7 @@ int fl_dsysv_batched(int batch, int n, double *A_dev, double *b_dev, int32_t *in
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FL_ERR_NO_DEVICE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     FL_GEO_DISPATCH(dsysv_kernel, n, A_dev, b_dev, info_dev);
-    return hipGetLastError() == hipSuccess ? FL_OK : FL_ERR_NO_DEVICE;
+    return fl::launch_status();
 }
 
 } // extern "C"

@@ -48,7 +48,17 @@ template <int NW, int EPT> struct Geo {
     static constexpr int T = NW * 64;
     static constexpr int NPAD = T * EPT;
     static constexpr int NCH = EPT / 2;
-    __device__ __forceinline__ static int e0(int c) { return ((c * T + (int)threadIdx.x) << 1); }
+    // The thread index behind an empty asm: index arithmetic derived from it is then redone where it is used
+    // (one or two integer instructions) instead of being hoisted out of the solver's main loop and kept -- or
+    // spilled -- for the whole kernel.  Measured on the code objects: fl_solve_kernel<2,8,DIAGQUAD,LBFGS> 217 -> 211
+    // VGPRs, the 4x8 BFGS kernels 12-44 spilled VGPRs -> 0.
+    __device__ __forceinline__ static int tid()
+    {
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        return t;
+    }
+    __device__ __forceinline__ static int e0(int c) { return ((c * T + tid()) << 1); }
 };
 
 __device__ __forceinline__ double uni(double v) { return LineSearch::uni(v); }
@@ -278,7 +288,10 @@ namespace fl {
 // AUG = 1 wraps the objective in the augmented Lagrangian with aug_m block-sphere
 // constraints c_j = sum_{i in block j} x_i^2 - 1 (blocks of n/aug_m) and runs the
 // reference's outer loop (NO.f90:2150-2185) around the inner solver.
-template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
+// EXACT (BFGS only): the exact-Hessian refresh (ExactStep > 0, NO.f90:674-682, 949-956) is compiled in.  The fused
+// kernels are instantiated both ways and the host picks by opt->exact_step, so that the ExactStep <= 0 kernel -- pure
+// quasi-Newton updates, BASELINE config 4 -- does not carry the Cholesky kernels' registers.
+template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == FL_SOLVER_BFGS)> struct Solver {
     using G = Geo<NW, EPT>;
     using Obj = Objective<OBJ, NW, EPT>;
     static constexpr int NPAD = G::NPAD;
@@ -352,6 +365,11 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
     int blk[AUG ? EPT : 1]; // constraint block of each of the thread's elements (-1 = padding)
 
     enum { PH_INIT = 0, PH_LS = 1, PH_DONE = 2, PH_HESS = 3 };
+    // internal continuations of advance() (they never leave it): every continuation is inlined ONCE and the
+    // branches only choose which one runs.  The first version called after_init_rest() / direction_and_begin() from
+    // two places each, which put four copies of the Cholesky kernels and two of every H pass into one kernel --
+    // 400-500 spilled VGPRs at 8 elements per thread.
+    enum { GO_INIT_REST = -1, GO_DIRECTION = -2, GO_REFRESH = -3, GO_INIT_TAIL = -4, GO_DIRECTION_TAIL = -5 };
 
     __device__ __forceinline__ Solver(const SolveArgs &A_, double *lds_)
         : A(A_), lds(lds_), prob(blockIdx.x), n(A_.n), R{lds_ + L_RED, 0}
@@ -374,14 +392,44 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
     }
     // LDS rows of the slot-th pair of the LDS ring (s row, then y row)
     __device__ __forceinline__ double *lds_pair(int slot) const { return lds + L_G0 + (size_t)(2 * slot) * NPAD; }
-    // where g_old waits during the line search
+    // where g_old waits during the line search (BFGS: in the second broadcast array -- the first one is the row
+    // buffer of the Cholesky kernels, which may run before g_old is wanted)
     __device__ __forceinline__ double *g0_park() const
     {
+        if constexpr (METHOD == FL_SOLVER_BFGS) return lds + L_BF + NPAD;
         if constexpr (LDS_PAIRS > 0) {
             const int next = (lrec + 1 == LDS_PAIRS) ? 0 : lrec + 1;
             return lds_pair(next) + NPAD;
         } else {
             return lds + L_G0;
+        }
+    }
+
+    // ---------------------------------------------------------------- register diet of the dense phases
+    // The dense phases (H passes, folds, Cholesky kernels) sweep whole matrices with blocks of columns in registers.
+    // At 8 elements per thread the machine's own vectors would not fit beside them (the first version spilled
+    // 200-500 VGPRs to scratch there), so for their duration the iterate waits in the caller's row x[prob][:] -- it
+    // IS the current iterate, init() read it from there and finish() writes it there -- and the objective's data
+    // (d, b of the diagonal quadratic) are re-read afterwards.  Every thread reads back only what it wrote.
+    static constexpr bool PARK = (EPT >= 8) && (METHOD == FL_SOLVER_BFGS || METHOD == FL_SOLVER_NEWTON);
+    // ... and the line search's scalars are pinned to scalar registers (the L-BFGS / CG kernels measured faster
+    // without: fl_linesearch.hpp)
+    // LEAN: what else is shed where 256 VGPRs per wave are short (dense kernels at 8 elements per thread; every
+    // 512-thread augmented-Lagrangian kernel): d, b of the diagonal quadratic are re-read per evaluation.
+    static constexpr bool LEAN = PARK || (AUG && NW >= 8);
+#ifndef FL_UNI_LEAN
+#define FL_UNI_LEAN 2
+#endif
+    static constexpr int UNI_LEVEL = LEAN ? FL_UNI_LEAN : FL_UNI_LEVEL;
+    __device__ __forceinline__ void park()
+    {
+        if constexpr (PARK && !HESS_RCI) store_user<NW, EPT>(A.x + (size_t)prob * n, n, x); // (RCI: x is already there)
+    }
+    __device__ __forceinline__ void unpark()
+    {
+        if constexpr (PARK) {
+            load_user<NW, EPT>(A.x + (size_t)prob * n, n, x);
+            obj.init(A, prob, lds + L_XS);
         }
     }
 
@@ -441,6 +489,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
     template <bool WANT_G = true> __device__ __forceinline__ void evaluate(double &f, double &gp, double &ggo)
     {
         double r[4];
+        if constexpr (LEAN) obj.init(A, prob, lds + L_XS); // d, b are re-read per evaluation instead of living in registers
         if constexpr (AUG && !WANT_G) {
             double gl[EPT]; // dead: the compiler drops the gradient arithmetic
             obj.eval(x, gl, r[0], r[1], n, lds + L_XS);
@@ -450,29 +499,30 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
         if constexpr (AUG) {
             // c_j: masked full-width sums of x^2 (one reduction of aug_m values with the objective's)
             const int m = A.aug_m;
-            double cj[FL_MAX_CONSTRAINTS];
-#pragma unroll
-            for (int j = 0; j < FL_MAX_CONSTRAINTS; ++j) {
-                cj[j] = 0.0;
+            // the thread's share of c_j + 1: its elements of block j squared, summed in element order (only the
+            // constraints of the reduction at hand are formed: 16 of them at once cost 32 VGPRs)
+            auto cpart = [&](int j) {
+                double acc = 0.0;
                 if (j < m) {
-                    double acc = 0.0;
 #pragma unroll
                     for (int k = 0; k < EPT; ++k) {
                         const double t = (blk[k] == j) ? x[k] * x[k] : 0.0;
                         acc = (k == 0) ? t : acc + t;
                     }
-                    cj[j] = acc;
                 }
-            }
+                return acc;
+            };
             double r2[2] = {r[0], r[1]};
             double *cxs = lds + L_CX;
             __syncthreads(); // readers of the previous trial's c(x) are done
-            if (m <= 8) { // the objective's two sums and up to 8 constraints in ONE reduction phase
+            if (NW < 8 && m <= 8) { // the objective's two sums and up to 8 constraints in ONE reduction phase
+                                    // (not in the 512-thread kernels: ten values at once cost them spills; every value's
+                                    // sum has the same order either way)
                 double q[10];
                 q[0] = r2[0];
                 q[1] = r2[1];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) q[2 + u] = cj[u];
+                for (int u = 0; u < 8; ++u) q[2 + u] = cpart(u);
                 R.run(q);
                 r2[0] = q[0];
                 r2[1] = q[1];
@@ -487,7 +537,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
                     if (j0 < m) {
                         double q[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) q[u] = cj[j0 + u];
+                        for (int u = 0; u < 4; ++u) q[u] = cpart(j0 + u);
                         R.run(q);
                         if (threadIdx.x == 0) {
 #pragma unroll
@@ -536,14 +586,38 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
         int rq;
         if (phase == PH_INIT) {
             rq = after_init(fv, gg_new);
-        } else if (phase == PH_HESS) { // the caller has written the Hessian it was asked for
-            rq = (hess_stage == 0) ? after_init_rest() : direction_and_begin();
+        } else if (HESS_RCI && phase == PH_HESS) { // the caller has written the Hessian it was asked for
+            rq = (hess_stage == 0) ? GO_INIT_REST : GO_DIRECTION;
         } else {
             gg = gg_new;
             rq = __builtin_amdgcn_readfirstlane(ls.step(fv, pv));
-            ls.uniformize();
+            ls.template uniformize<UNI_LEVEL>();
             if (rq == 0) rq = after_linesearch();
         }
+        bool initial = false, refreshed = false;
+        if (rq == GO_INIT_REST) {
+            initial = true;
+            rq = after_init_rest();
+        }
+        if (rq == GO_DIRECTION) rq = direction_head();
+        if constexpr (METHOD == FL_SOLVER_BFGS && EXACT) {
+            if (rq == GO_REFRESH) { // the one copy of the Cholesky kernels
+                refreshed = bfgs_exact_refresh();
+                if (initial) {
+                    if (refreshed) {
+                        h_valid = 1;
+                        status = FL_STATUS_MAXIT;
+                        rq = begin_linesearch();
+                    } else {
+                        rq = GO_INIT_TAIL;
+                    }
+                } else {
+                    rq = GO_DIRECTION_TAIL;
+                }
+            }
+        }
+        if (rq == GO_INIT_TAIL) rq = after_init_tail();
+        if (rq == GO_DIRECTION_TAIL) rq = direction_and_begin(refreshed);
         pending = rq;
         return rq;
     }
@@ -575,7 +649,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
         const int strong = (METHOD == FL_SOLVER_CG && A.cg_method == FL_CG_PR) ? 1 : A.strong;
         phase = PH_LS;
         const int rq = __builtin_amdgcn_readfirstlane(ls.begin(strong, fused, A.c1, A.c2, A.incr, a, fnew, phid));
-        ls.uniformize();
+        ls.template uniformize<UNI_LEVEL>();
         return rq;
     }
 
@@ -591,7 +665,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
                 return FL_REQ_H | FL_REQ_SAME;
             }
         }
-        return after_init_rest();
+        return GO_INIT_REST;
     }
     __device__ __forceinline__ int after_init_rest()
     {
@@ -599,13 +673,13 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
             status = FL_STATUS_MAXIT;
             if (newton_direction(true)) return begin_linesearch();
         }
-        if constexpr (METHOD == FL_SOLVER_BFGS) { // NO.f90:674-682: exact inverse Hessian first, if asked for
-            if (A.exact_step > 0 && bfgs_exact_refresh()) {
-                h_valid = 1;
-                status = FL_STATUS_MAXIT;
-                return begin_linesearch();
-            }
+        if constexpr (METHOD == FL_SOLVER_BFGS && EXACT) { // NO.f90:674-682: exact inverse Hessian first, if asked for
+            if (A.exact_step > 0) return GO_REFRESH;
         }
+        return GO_INIT_TAIL;
+    }
+    __device__ __forceinline__ int after_init_tail()
+    {
 #pragma unroll
         for (int k = 0; k < EPT; ++k) p[k] = -g[k];
         phid = -gg; // p=-fdnew; phidnew=-dot_product(fdnew,fdnew)
@@ -675,14 +749,17 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
     {
         double *Hm = hist_base();
         fill_hessian(Hm);
+        park();
         const int info = DN::cholesky(Hm, n, lds + L_BF, lds + L_CX);
 #pragma unroll
         for (int k = 0; k < EPT; ++k) p[k] = -g[k];
         if (info == 0) {
             DN::solve(Hm, n, p, R, lds + L_CX);
+            unpark();
             direction_scalars();
             return true;
         }
+        unpark();
         if (!initial) { // Hessian is not positive definite, use steepest descent direction (NO.f90:1235-1236)
             phid = -gg;
             pp = gg;
@@ -694,13 +771,28 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
     __device__ __forceinline__ bool bfgs_exact_refresh()
     {
         double *Hm = hist_base(), *U = Hm + (size_t)n * NPAD, *W = U + (size_t)n * NPAD;
+        double *gbuf = lds + L_BF + 2 * NPAD; // third broadcast array: g waits here (the Cholesky kernels use the first)
         fill_hessian(U);
-        if (DN::cholesky(U, n, lds + L_BF, lds + L_CX) != 0) return false;
-        DN::inverse_factor(U, W, n, lds + L_BF);
-        DN::wtw(W, Hm, n, lds + L_BF);
+        park();
+        if constexpr (PARK) {
+            store_pad<NW, EPT>(gbuf, g);
+            store_pad<NW, EPT>(W, x0); // wanted again only if the factorisation fails -- and then W is still untouched
+        }
+        const int info = DN::cholesky(U, n, lds + L_BF, lds + L_CX);
+        if (info == 0) {
+            DN::inverse_factor(U, W, n, lds + L_BF);
+            DN::wtw(W, Hm, n, lds + L_BF);
+        }
+        if constexpr (PARK) load_pad<NW, EPT>(gbuf, g);
+        if (info != 0) {
+            if constexpr (PARK) load_pad<NW, EPT>(W, x0);
+            unpark();
+            return false;
+        }
         ndef = 0; // pending updates belonged to the matrix that has just been replaced
         h_ident = 0;
-        neg_matvec(Hm, lds + L_BF + 2 * NPAD);
+        neg_matvec(Hm, gbuf);
+        unpark();
         direction_scalars();
         return true;
     }
@@ -730,12 +822,21 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
                 return FL_REQ_H | FL_REQ_SAME;
             }
         }
-        return direction_and_begin();
+        return GO_DIRECTION;
     }
-    __device__ __forceinline__ int direction_and_begin()
+    // After(): every ExactStep-th main-loop iteration BFGS tries the exact inverse Hessian first (i=mod(iIteration,freq),
+    // NO.f90:949-956)
+    __device__ __forceinline__ int direction_head()
+    {
+        if constexpr (METHOD == FL_SOLVER_BFGS && EXACT) {
+            if (A.exact_step > 0 && h_valid && main_it % A.exact_step == 0) return GO_REFRESH;
+        }
+        return GO_DIRECTION_TAIL;
+    }
+    __device__ __forceinline__ int direction_and_begin(bool refreshed)
     {
         double g0[EPT];
-        if constexpr (NEEDS_G0) load_pad<NW, EPT>(g0_park(), g0);
+        if constexpr (NEEDS_G0 && METHOD != FL_SOLVER_BFGS) load_pad<NW, EPT>(g0_park(), g0);
         if constexpr (METHOD == FL_SOLVER_SD) { // NO.f90:185-186
 #pragma unroll
             for (int k = 0; k < EPT; ++k) p[k] = -g[k];
@@ -749,13 +850,10 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
         } else if constexpr (METHOD == FL_SOLVER_NEWTON) {
             newton_direction(false);
         } else {
-            // After(): every ExactStep-th main-loop iteration try the exact inverse Hessian (i=mod(iIteration,freq),
-            // NO.f90:949-956); otherwise, or if it is not positive definite, the rank-2 update (957-963)
-            bool refreshed = false;
-            if (A.exact_step > 0 && h_valid && main_it % A.exact_step == 0) refreshed = bfgs_exact_refresh();
+            // without a fresh exact inverse Hessian (not due, or not positive definite): the rank-2 update (NO.f90:957-963)
             if (!refreshed) {
-                if constexpr (BF_DEFER > 0) direction_bfgs_deferred(g0);
-                else direction_bfgs(g0);
+                if constexpr (BF_DEFER > 0) direction_bfgs_deferred();
+                else direction_bfgs();
             }
             h_valid = 1;
         }
@@ -956,17 +1054,22 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
     // H = a I, NO.f90:711-715).  Two streaming passes over the column-major H [n][NPAD]:
     //   pass 1: q = H y           (reads 8 n^2 B; "axpy" form, no reductions: q_i sums over j in order)
     //   pass 2: H' written in place while p = -H' g accumulates (reads + writes 16 n^2 B)
-    __device__ __forceinline__ void direction_bfgs(const double (&g0)[EPT])
+    __device__ __forceinline__ void direction_bfgs()
     {
         double *H = hist_base();
         double *bs = lds + L_BF, *bq = bs + NPAD, *bg = bq + NPAD;
         const bool first = !h_valid; // first quasi-Newton matrix from H = a I (NO.f90:711-715)
         double sv[EPT], yv[EPT], q[EPT];
+        {
+            double g0[EPT];
+            load_pad<NW, EPT>(g0_park(), g0); // (the second broadcast array: read before bq is written below)
 #pragma unroll
-        for (int k = 0; k < EPT; ++k) {
-            sv[k] = x[k] - x0[k]; // s=x-s
-            yv[k] = g[k] - g0[k]; // y=fdnew-y
+            for (int k = 0; k < EPT; ++k) {
+                sv[k] = x[k] - x0[k]; // s=x-s
+                yv[k] = g[k] - g0[k]; // y=fdnew-y
+            }
         }
+        park();
         double r1[1] = {dot_part<EPT>(yv, sv)};
         R.run(r1);
         const double rho = uni(1.0 / r1[0]); // rho=1d0/dot_product(y,s)
@@ -1040,6 +1143,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
         }
 #pragma unroll
         for (int k = 0; k < EPT; ++k) p[k] = -acc[k]; // p=-matmul(H,fdnew)
+        unpark();
         double r3[2] = {dot_part<EPT>(g, p), dot_part<EPT>(p, p)};
         R.run(r3);
         phid = r3[0];
@@ -1053,17 +1157,22 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
     // 4 dot products and two axpy-like corrections per pending update; the new update joins the list, p = -H_new g
     // follows algebraically, and every BF_DEFER-th iteration the list is folded into H element by element in the
     // order the updates occurred.  HBM bytes per iteration: 8 n^2 + 16 n^2 / BF_DEFER instead of 24 n^2.
-    __device__ __forceinline__ void direction_bfgs_deferred(const double (&g0)[EPT])
+    __device__ __forceinline__ void direction_bfgs_deferred()
     {
         double *H = hist_base(), *D = deferred_rows();
         double *by = lds + L_BF, *bg = by + NPAD;
         double *drho = lds + L_DEF, *dcs = drho + (BF_DEFER > 0 ? BF_DEFER : 1);
         double sv[EPT], yv[EPT], q[EPT], w[EPT];
+        {
+            double g0[EPT];
+            load_pad<NW, EPT>(g0_park(), g0); // (= bg's array: read before g is broadcast below)
 #pragma unroll
-        for (int k = 0; k < EPT; ++k) {
-            sv[k] = x[k] - x0[k];
-            yv[k] = g[k] - g0[k];
+            for (int k = 0; k < EPT; ++k) {
+                sv[k] = x[k] - x0[k];
+                yv[k] = g[k] - g0[k];
+            }
         }
+        park();
         double r1[1] = {dot_part<EPT>(yv, sv)};
         R.run(r1);
         const double rho = uni(1.0 / r1[0]);
@@ -1131,7 +1240,20 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
         }
         ++ndef;
         __syncthreads(); // rho_l, cs_l and the rows of this update are visible to the workgroup
-        if (ndef == BF_DEFER) bfgs_fold();
+        if (ndef == BF_DEFER) {
+            // the fold keeps the row factors of all pending updates in registers: g and p wait in the second and
+            // third broadcast arrays meanwhile (the fold's staging area is inside the first)
+            if constexpr (PARK) {
+                store_pad<NW, EPT>(lds + L_BF + NPAD, g);
+                store_pad<NW, EPT>(lds + L_BF + 2 * NPAD, p);
+            }
+            bfgs_fold();
+            if constexpr (PARK) {
+                load_pad<NW, EPT>(lds + L_BF + NPAD, g);
+                load_pad<NW, EPT>(lds + L_BF + 2 * NPAD, p);
+            }
+        }
+        unpark();
         double r4[2] = {dot_part<EPT>(g, p), dot_part<EPT>(p, p)};
         R.run(r4);
         phid = r4[0];
@@ -1147,7 +1269,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
         double *H = hist_base(), *D = deferred_rows();
         double *stage = lds + L_BF; // [2*J][CB]
         const double *drho = lds + L_DEF, *dcs = drho + J;
-        static_assert(BF_DEFER == 0 || 2 * J * CB <= 3 * NPAD, "staging area");
+        static_assert(BF_DEFER == 0 || 2 * J * CB <= NPAD, "staging area inside the first broadcast array");
         for (int c = 0; c < G::NCH; ++c) {
             const int e = G::e0(c);
             double rq[J][2], rs[J][2], cf[J][2];
@@ -1162,7 +1284,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
             }
             for (int jb = 0; jb < n; jb += CB) {
                 __syncthreads(); // the previous block's readers are done
-                for (int i = threadIdx.x; i < 2 * J * CB; i += G::T) {
+                for (int i = G::tid(); i < 2 * J * CB; i += G::T) {
                     const int row = i / CB, col = i - row * CB;
                     stage[i] = (jb + col < n) ? D[(size_t)row * NPAD + jb + col] : 0.0;
                 }
@@ -1206,7 +1328,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
         store_pad<NW, EPT>(vec + 3 * NPAD, g);
         if constexpr (NEEDS_G0) {
             double g0[EPT];
-            load_pad<NW, EPT>(lds + L_G0, g0);
+            load_pad<NW, EPT>(g0_park(), g0);
             store_pad<NW, EPT>(vec + 2 * NPAD, g0);
         }
         if constexpr (METHOD == FL_SOLVER_LBFGS) {
@@ -1236,7 +1358,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> struct Solver {
         if constexpr (NEEDS_G0) {
             double g0[EPT];
             load_pad<NW, EPT>(vec + 2 * NPAD, g0);
-            store_pad<NW, EPT>(lds + L_G0, g0);
+            store_pad<NW, EPT>(g0_park(), g0);
         }
         if constexpr (METHOD == FL_SOLVER_LBFGS) {
             if (threadIdx.x < FL_MAX_MEMORY) lds[L_RHO + threadIdx.x] = rho[threadIdx.x];

@@ -65,24 +65,25 @@ struct LineSearch {
         return v;
 #endif
     }
-    FL_HD void uniformize()
-    {
-        // Measured on the north-star workload (profiles/r01/geometry_ab.txt): pinning the whole
-        // machine pushes the kernel over the SGPR budget and the spills (v_readlane) cost more
-        // than the occupancy gains: level 0 = 25.8, 1 = 23.4, 2 = 23.0 M it/s.
 #ifndef FL_UNI_LEVEL
 #define FL_UNI_LEVEL 0
 #endif
-#if FL_UNI_LEVEL >= 1 // the values every trial touches
-        c2abs = uni(c2abs); fx0 = uni(fx0); phid0 = uni(phid0);
-        a = uni(a); aold = uni(aold); fx = uni(fx); fold = uni(fold); phidnew = uni(phidnew); phidold = uni(phidold);
-        a_eval = uni(a_eval);
-#endif
-#if FL_UNI_LEVEL >= 2 // zoom's bracket and the constants
-        c1 = uni(c1); incr = uni(incr);
-        low = uni(low); up = uni(up); flow = uni(flow); fup = uni(fup); phidlow = uni(phidlow); phidup = uni(phidup);
-        plma = uni(plma);
-#endif
+    template <int LEVEL = FL_UNI_LEVEL> FL_HD void uniformize()
+    {
+        // Measured on the north-star workload (profiles/r01/geometry_ab.txt): pinning the whole
+        // machine pushes the kernel over the SGPR budget and the spills (v_readlane) cost more
+        // than the occupancy gains: level 0 = 25.8, 1 = 23.4, 2 = 23.0 M it/s.  The dense kernels at 8
+        // elements per thread use level 2: there the vector registers are what is short.
+        if constexpr (LEVEL >= 1) { // the values every trial touches
+            c2abs = uni(c2abs); fx0 = uni(fx0); phid0 = uni(phid0);
+            a = uni(a); aold = uni(aold); fx = uni(fx); fold = uni(fold); phidnew = uni(phidnew); phidold = uni(phidold);
+            a_eval = uni(a_eval);
+        }
+        if constexpr (LEVEL >= 2) { // zoom's bracket and the constants
+            c1 = uni(c1); incr = uni(incr);
+            low = uni(low); up = uni(up); flow = uni(flow); fup = uni(fup); phidlow = uni(phidlow); phidup = uni(phidup);
+            plma = uni(plma);
+        }
 #if defined(__HIP_DEVICE_COMPILE__)
         st = __builtin_amdgcn_readfirstlane(st);
         zret = __builtin_amdgcn_readfirstlane(zret);

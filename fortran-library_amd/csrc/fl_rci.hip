@@ -15,6 +15,7 @@
 // manglings): steepestdescent, conjugategradient(_basic), lbfgs, bfgs -- batch of one,
 // callbacks evaluated on the host, x copied device <-> host per evaluation.
 #include "fl_device.hpp"
+#include "fl_host.hpp"
 #include "fl_big.hpp"
 #include <cmath>
 #include <cstdio>
@@ -50,8 +51,8 @@ __global__ __launch_bounds__(NW * 64) void rci_step_kernel(SolveArgs A, int firs
             return;
         }
         double ggv = s.gg;
-        if (s.pending & FL_REQ_F) fv = f_dev[prob];
-        if (s.pending & FL_REQ_G) {
+        if ((s.pending & FL_REQ_F) && f_dev) fv = f_dev[prob];
+        if ((s.pending & FL_REQ_G) && g_dev) {
             load_user<NW, EPT>(g_dev + (size_t)prob * n, n, s.g);
             double q[2] = {dot_part<EPT>(s.g, s.p), dot_part<EPT>(s.g, s.g)};
             s.R.run(q);
@@ -95,8 +96,8 @@ __global__ __launch_bounds__(1024) void rci_step_big_kernel(SolveArgs A, int fir
             return;
         }
         double ggv = s.gg;
-        if (s.pending & FL_REQ_F) fv = f_dev[prob];
-        if (s.pending & FL_REQ_G) s.take_gradient(g_dev + (size_t)prob * n, pv, ggv);
+        if ((s.pending & FL_REQ_F) && f_dev) fv = f_dev[prob];
+        if ((s.pending & FL_REQ_G) && g_dev) s.take_gradient(g_dev + (size_t)prob * n, pv, ggv);
         rq = s.advance(fv, pv, ggv);
     }
     if (rq == 0) s.finish();
@@ -309,7 +310,8 @@ int fl_rci_create(fl_rci **out, int solver, int batch, int n, const fl_options *
 int fl_rci_step(fl_rci *h, double *x_dev, const double *f_dev, const double *g_dev, int32_t *request_dev)
 {
     if (!h || !x_dev || !request_dev) return FL_ERR_INVALID_ARGUMENT;
-    if (!h->r.first && (!f_dev || !g_dev)) return FL_ERR_INVALID_ARGUMENT;
+    // f_dev / g_dev may be NULL on a step where no problem asked for them (the first step; a step that only delivers
+    // Hessians, FL_REQ_H): the kernels read an array only for the problems whose request bit names it
     fl::Rci *r = &h->r;
     r->A.x = x_dev;
     const int nw = r->nw, ept = r->ept;
@@ -321,7 +323,7 @@ int fl_rci_step(fl_rci *h, double *x_dev, const double *f_dev, const double *g_d
     else if (nw == 4 && ept == 8) fl::launch_rci<4, 8>(r, f_dev, g_dev, request_dev);
     else fl::launch_rci<8, 8>(r, f_dev, g_dev, request_dev);
     r->first = 0;
-    return hipGetLastError() == hipSuccess ? FL_OK : FL_ERR_NO_DEVICE;
+    return fl::launch_status();
 }
 
 int fl_rci_hessian_buffer(fl_rci *h, double **hessian_dev, int *ld)
@@ -348,7 +350,7 @@ int fl_rci_results(fl_rci *h, double *f_dev, double *gg_dev, int32_t *iters_dev,
     if (status_dev) ok &= hipMemcpyAsync(status_dev, h->r.status, B * 4, hipMemcpyDeviceToDevice, st) == hipSuccess;
     if (nf_dev) ok &= hipMemcpyAsync(nf_dev, h->r.nf, B * 4, hipMemcpyDeviceToDevice, st) == hipSuccess;
     if (ng_dev) ok &= hipMemcpyAsync(ng_dev, h->r.ng, B * 4, hipMemcpyDeviceToDevice, st) == hipSuccess;
-    return ok ? FL_OK : FL_ERR_NO_DEVICE;
+    return ok ? FL_OK : FL_ERR_LAUNCH;
 }
 
 // ------------------------------------------------------------------ legacy entry points
@@ -467,7 +469,7 @@ static int legacy_solve(int solver, const char *name, const HostObjective &ob, d
     if (gd) (void)hipFree(gd);
     if (rqd) (void)hipFree(rqd);
     fl_rci_destroy(h);
-    return ok ? status : FL_ERR_NO_DEVICE;
+    return ok ? status : FL_ERR_LAUNCH;
 }
 
 // One line search with host callbacks (the public Wolfe / StrongWolfe procedures).  On exit, like the reference:

@@ -100,7 +100,11 @@ template <int NW> struct Reducer {
             else if constexpr (NV % 4 == 1) q[g] = wave_reduce_group<1>(v + g * 4);
         }
         if constexpr (NW > 1) {
-            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            // 512-thread kernels (256 VGPRs per wave): recompute the slot indices here instead of keeping them
+            // (or spilling them) across the whole solver loop -- see Geo::tid()
+            int tx = threadIdx.x;
+            if constexpr (NW >= 8) asm volatile("" : "+v"(tx));
+            const int lane = tx & 63, wave = tx >> 6;
             double *s = slots + parity * (NVMAX * NW);
             // row r of a full group holds value ((r & 1) << 1) | (r >> 1); partial groups: see wave_reduce_group
             const int row = lane >> 4;

@@ -11,6 +11,7 @@
 //     problem and the hardware dispatcher back-fills CUs as workgroups retire (no
 //     lock-step batch, no host round trips).
 #include "fl_device.hpp"
+#include "fl_host.hpp"
 #include "fl_big.hpp"
 
 #ifdef FL_MIN_WPE
@@ -21,10 +22,10 @@
 
 namespace fl {
 
-template <int NW, int EPT, int OBJ, int METHOD, int AUG>
+template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = 0>
 __global__ __launch_bounds__(NW * 64) FL_OCC_ATTR void fl_solve_kernel(SolveArgs A)
 {
-    using S = Solver<NW, EPT, OBJ, METHOD, AUG>;
+    using S = Solver<NW, EPT, OBJ, METHOD, AUG, EXACT>;
 #ifndef FL_LDS_PAD // tuning knob: extra LDS per workgroup caps the workgroups resident per CU
 #define FL_LDS_PAD 0
 #endif
@@ -35,16 +36,20 @@ __global__ __launch_bounds__(NW * 64) FL_OCC_ATTR void fl_solve_kernel(SolveArgs
     double fv = 0.0, pv = 0.0, gg = 0.0;
     bool have_g = false; // augmented Lagrangian: objective-only trials skip the gradient until it is asked for
     while (rq) {
+        // which evaluation the request needs (each form is inlined once)
+        bool f_only = false, full = false;
         if (!(rq & FL_REQ_SAME)) {
             if (!(rq & FL_REQ_NOMOVE)) s.move(s.request_point());
-            if (AUG && !(rq & FL_REQ_G)) {
-                s.template evaluate<false>(fv, pv, gg);
-                have_g = false;
-            } else {
-                s.template evaluate<true>(fv, pv, gg);
-                have_g = true;
-            }
+            if (AUG && !(rq & FL_REQ_G)) f_only = true;
+            else full = true;
         } else if (AUG && (rq & FL_REQ_G) && !have_g) { // gradient at the point whose objective is already known
+            full = true;
+        }
+        if (AUG && f_only) {
+            s.template evaluate<false>(fv, pv, gg);
+            have_g = false;
+        }
+        if (full) {
             s.template evaluate<true>(fv, pv, gg);
             have_g = true;
         }
@@ -121,9 +126,10 @@ static bool select_geometry(int n, GeoSel &g)
     return true;
 }
 
-template <int NW, int EPT, int OBJ, int METHOD, int AUG> static hipError_t launch_k(const SolveArgs &A, hipStream_t st)
+template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = 0>
+static hipError_t launch_k(const SolveArgs &A, hipStream_t st)
 {
-    hipLaunchKernelGGL((fl_solve_kernel<NW, EPT, OBJ, METHOD, AUG>), dim3(A.batch), dim3(NW * 64), 0, st, A);
+    hipLaunchKernelGGL((fl_solve_kernel<NW, EPT, OBJ, METHOD, AUG, EXACT>), dim3(A.batch), dim3(NW * 64), 0, st, A);
     return hipGetLastError();
 }
 template <int NW, int EPT, int OBJ> static hipError_t launch_m(int method, int aug, const SolveArgs &A, hipStream_t st)
@@ -135,7 +141,9 @@ template <int NW, int EPT, int OBJ> static hipError_t launch_m(int method, int a
     switch (method) {
     case FL_SOLVER_SD: return launch_k<NW, EPT, OBJ, FL_SOLVER_SD, 0>(A, st);
     case FL_SOLVER_CG: return launch_k<NW, EPT, OBJ, FL_SOLVER_CG, 0>(A, st);
-    case FL_SOLVER_BFGS: return launch_k<NW, EPT, OBJ, FL_SOLVER_BFGS, 0>(A, st);
+    case FL_SOLVER_BFGS: // the exact-Hessian refresh (Cholesky kernels) is compiled into its own instantiation
+        if (A.exact_step > 0) return launch_k<NW, EPT, OBJ, FL_SOLVER_BFGS, 0, 1>(A, st);
+        return launch_k<NW, EPT, OBJ, FL_SOLVER_BFGS, 0, 0>(A, st);
     case FL_SOLVER_NEWTON: return launch_k<NW, EPT, OBJ, FL_SOLVER_NEWTON, 0>(A, st);
     default: return launch_k<NW, EPT, OBJ, FL_SOLVER_LBFGS, 0>(A, st);
     }
@@ -258,14 +266,18 @@ static int solve(int method, int objective, int batch, int n, double *x, const d
         } else if (method == FL_SOLVER_BFGS) {
             rows = static_cast<double *>(ws) + (size_t)batch * BigSolver<FL_OBJ_QUARTIC, FL_SOLVER_BFGS>::bfgs_rows(n) * npad;
         } else if (hipMallocAsync((void **)&rows, rows_bytes, st) != hipSuccess) {
+            (void)hipGetLastError(); // the failed allocation must not taint the caller's next call
             return FL_ERR_WORKSPACE;
         }
         hipError_t e = launch_big(objective, method, A, rows, st);
-        if (own_rows) (void)hipFreeAsync(rows, st);
-        return e == hipSuccess ? FL_OK : FL_ERR_NO_DEVICE;
+        if (own_rows) { // stream-ordered: the rows are released once the kernel above has finished
+            const hipError_t ef = hipFreeAsync(rows, st);
+            if (e == hipSuccess) e = ef;
+        }
+        return launch_status(e);
     }
     hipError_t e = launch(g, objective, method, aug != nullptr, A, st);
-    return e == hipSuccess ? FL_OK : FL_ERR_NO_DEVICE;
+    return launch_status(e);
 }
 
 } // namespace fl

@@ -27,7 +27,7 @@
  * stream); outputs are valid after the stream is synchronised.  Return value:
  * FL_OK or a negative FL_ERR_* code; nothing is printed and nothing runs on the
  * CPU as a fallback -- without a usable HIP device every call fails with
- * FL_ERR_NO_DEVICE.
+ * FL_ERR_NO_DEVICE; a launch the runtime refuses is FL_ERR_LAUNCH.
  */
 #ifndef FL_NLOPT_H
 #define FL_NLOPT_H
@@ -42,7 +42,8 @@ extern "C" {
 #define FL_ERR_UNSUPPORTED_SIZE (-2) /* Memory > FL_MAX_MEMORY; n > 4096 for NewtonRaphson, BFGS with exact_step > 0 and */
                                      /* the augmented Lagrangian; n > 16384 for BFGS; n > 2^27 for SD / CG / L-BFGS      */
 #define FL_ERR_WORKSPACE (-3)        /* workspace missing or too small */
-#define FL_ERR_NO_DEVICE (-4)        /* no HIP device / kernel launch failed */
+#define FL_ERR_NO_DEVICE (-4)        /* no usable HIP device (hipGetDeviceCount), decided before anything is launched */
+#define FL_ERR_LAUNCH (-5)           /* a kernel launch or a stream-ordered allocation was refused by the runtime */
 
 /* built-in objectives (SURVEY.md section 8d synthetic inputs) */
 #define FL_OBJ_QUARTIC 0    /* f = sum x_i^4                      (test/test.f90:630-663)        */

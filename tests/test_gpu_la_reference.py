@@ -1,0 +1,127 @@
+"""-m gpu: the HIP dense kernels against the REFERENCE's LinearAlgebra routines (tests/golden/la_ref.npz, written by
+tools/make_la_golden.py from the unmodified reference module + MKL; no oracle and no /root/reference at run time).
+
+  fl_dposv_batched   <- My_dposv   LA.f90:719-730      fl_dpotri_batched <- My_dpotri 798-812 + dsyL2U 260-265
+  fl_dsysv_batched   <- My_dsysv   695-703
+  __linearalgebra_MOD_my_dgemm / _my_dgemm_t <- My_dgemm / My_dgemm_T 182-196 (cpp/FortranLibrary.hpp:48-63)
+  __linearalgebra_MOD_my_dsyev <- My_dsyev 879-887
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "fortran-library_amd"))
+import la_cases as LC
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+FIX = np.load(os.path.join(ROOT, "tests", "golden", "la_ref.npz"))
+dp = C.POINTER(C.c_double)
+
+
+def _nlo():
+    import FortranLibrary.NonlinearOptimization as NLO
+    return NLO
+
+
+def _fl():
+    from FortranLibrary.basic import FL
+    return FL
+
+
+def _padded(A, ld):
+    n = A.shape[0]
+    P = np.zeros((1, n, ld))
+    P[0, :, :n] = A.T  # column-major [n][ld]: row j of the array is column j of the matrix (symmetric here anyway)
+    return P
+
+
+def test_inputs():
+    assert np.array_equal(LC.input_digest(), FIX["input_digest"])
+
+
+@pytest.mark.parametrize("n", LC.SPD_SIZES)
+def test_dposv_and_dpotri_kernels_match_the_reference(n):
+    NLO = _nlo()
+    dev = torch.device("cuda:0")
+    T, E = NLO.reduction_geometry(n)
+    ld = T * E
+    A, b = LC.spd_case(n)
+    Ad, bd = torch.tensor(_padded(A, ld), device=dev), torch.tensor(b[None, :].copy(), device=dev)
+    info = NLO.dposv(Ad, bd).cpu().numpy()
+    assert list(info) == [int(FIX[f"dposv_info_{n}"])] == [0]
+    x, ref = bd.cpu().numpy()[0], FIX[f"dposv_x_{n}"]
+    assert np.abs(x - ref).max() <= 2e-13 * max(1.0, np.abs(ref).max())
+    L = np.tril(Ad.cpu().numpy()[0, :, :n].T)  # A harvests the Cholesky factor (LA.f90:717)
+    LC.compare_matrix(FIX, f"dposv_L_{n}", L, n, rtol=2e-13)
+    Ad = torch.tensor(_padded(A, ld), device=dev)
+    info = NLO.dpotri(Ad).cpu().numpy()
+    assert list(info) == [int(FIX[f"dpotri_info_{n}"])] == [0]
+    inv = Ad.cpu().numpy()[0, :, :n].T
+    assert np.array_equal(inv, inv.T)  # dsyL2U: both triangles
+    LC.compare_matrix(FIX, f"dpotri_{n}", np.tril(inv), n, rtol=2e-13)
+
+
+@pytest.mark.parametrize("n", LC.NONSPD_SIZES)
+def test_kernels_report_the_reference_info_when_not_positive_definite(n):
+    NLO = _nlo()
+    dev = torch.device("cuda:0")
+    T, E = NLO.reduction_geometry(n)
+    A, b = LC.nonspd_case(n)
+    Ad, bd = torch.tensor(_padded(A, T * E), device=dev), torch.tensor(b[None, :].copy(), device=dev)
+    assert list(NLO.dposv(Ad, bd).cpu().numpy()) == [int(FIX[f"nonspd_dposv_info_{n}"])]
+    assert np.array_equal(bd.cpu().numpy()[0], FIX[f"nonspd_dposv_x_{n}"])  # b untouched
+    Ad = torch.tensor(_padded(A, T * E), device=dev)
+    assert list(NLO.dpotri(Ad).cpu().numpy()) == [int(FIX[f"nonspd_dpotri_info_{n}"])]
+
+
+@pytest.mark.parametrize("n", LC.SYM_SIZES)
+def test_dsysv_kernel_matches_the_reference(n):
+    NLO = _nlo()
+    dev = torch.device("cuda:0")
+    T, E = NLO.reduction_geometry(n)
+    A, b = LC.indefinite_case(n)
+    Ad, bd = torch.tensor(_padded(A, T * E), device=dev), torch.tensor(b[None, :].copy(), device=dev)
+    assert list(NLO.dsysv(Ad, bd).cpu().numpy()) == [0]
+    x, ref = bd.cpu().numpy()[0], FIX[f"dsysv_x_{n}"]
+    assert np.abs(x - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("shape", LC.GEMM_SHAPES)
+def test_my_dgemm_symbols_match_the_reference(shape):
+    FL = _fl()
+    m, k, n = shape
+    A, B = LC.gemm_case(m, k, n)
+    At = np.asfortranarray(A.T.copy())
+    iM, iK, iN = C.c_int(m), C.c_int(k), C.c_int(n)
+    # |C_ij| ~ sqrt(k); two orders of summation of k products differ by ~ sqrt(k) eps |a||b|
+    tol = 1e-13 * np.sqrt(k)
+    Cm = np.asfortranarray(np.zeros((m, n)))
+    FL.__linearalgebra_MOD_my_dgemm(A.ctypes.data_as(dp), B.ctypes.data_as(dp), Cm.ctypes.data_as(dp), C.byref(iM),
+                                    C.byref(iK), C.byref(iN))
+    LC.compare_matrix(FIX, f"dgemm_{m}x{k}x{n}", Cm, max(m, n), rtol=tol, scale=np.sqrt(k))
+    Cm = np.asfortranarray(np.zeros((m, n)))
+    FL.__linearalgebra_MOD_my_dgemm_t(At.ctypes.data_as(dp), B.ctypes.data_as(dp), Cm.ctypes.data_as(dp), C.byref(iM),
+                                      C.byref(iK), C.byref(iN))
+    LC.compare_matrix(FIX, f"dgemmT_{m}x{k}x{n}", Cm, max(m, n), rtol=tol, scale=np.sqrt(k))
+
+
+@pytest.mark.parametrize("n", LC.EIG_SIZES)
+def test_my_dsyev_symbol_matches_the_reference(n):
+    FL = _fl()
+    A = LC.eig_case(n)
+    norm = np.abs(A).sum(axis=1).max()
+    for job in (b"N", b"V"):
+        S = np.asfortranarray(np.tril(A))  # only the lower triangle is referenced ('L', LA.f90:886)
+        w = np.zeros(n)
+        FL.__linearalgebra_MOD_my_dsyev(job, S.ctypes.data_as(dp), w.ctypes.data_as(dp), C.byref(C.c_int(n)), C.c_int(1))
+        ref = FIX[f"dsyev_{job.decode()}_{n}"]
+        assert np.all(np.diff(w) >= 0)  # ascending
+        assert np.abs(w - ref).max() <= 1e-12 * norm
+        if job == b"V":  # eigenvectors are defined up to sign (and rotation in near-degenerate pairs): residuals
+            assert np.abs(A @ S - S * w[None, :]).max() <= max(50 * float(FIX[f"dsyev_V_resid_{n}"]), 1e-12 * norm)
+            assert np.abs(S.T @ S - np.eye(n)).max() <= max(50 * float(FIX[f"dsyev_V_orth_{n}"]), 1e-12)
