@@ -77,7 +77,12 @@ template <int OBJ, int METHOD> struct BigSolver {
     __host__ __device__ static size_t bfgs_rows(int n) { return (size_t)n + 2 * BF_DEFER + 1; }
 
     // ---- element pairs
-    __device__ __forceinline__ int e_of(int c) const { return (c * T + tid) << 1; }
+    __device__ __forceinline__ int e_of(int c) const // (thread index behind an empty asm: see Geo::tid())
+    {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        return (c * T + t) << 1;
+    }
     __device__ __forceinline__ void ldu(const double *row, int e, double &u, double &v) const
     {
         if (ual && e + 1 < n) {
@@ -734,10 +739,10 @@ template <int OBJ, int METHOD> struct BigSolver {
         }
         ++ndef;
         R.run(r4); // (its barrier also publishes rho_l, cs_l and the new rows)
-        if (ndef == BF_DEFER) bfgs_fold();
-        phid = r4[0];
-        pp = r4[1];
+        phid = uni(r4[0]); // finished -- two scalars -- before the fold: left pending, the reduction's 32 partial sums
+        pp = uni(r4[1]);   // stay in vector registers across it
         a = 1.0;
+        if (ndef == BF_DEFER) bfgs_fold();
     }
     // H <- H with the pending updates applied in order: one ELEMENT row per thread and sweep (the row factors of
     // the eight pending updates for one row are 24 doubles; for a 16-byte pair they were 96 VGPRs of the 128)
@@ -766,6 +771,7 @@ template <int OBJ, int METHOD> struct BigSolver {
                 }
                 __syncthreads();
                 const int jend = (n - jb < CB) ? n - jb : CB;
+#pragma unroll 2
                 for (int jj = 0; jj < jend; ++jj) {
                     const int j = jb + jj;
                     double *hp = H + (size_t)j * npad + e;
@@ -824,9 +830,26 @@ template <int OBJ, int METHOD> struct BigSolver {
         recent = *iq++; cnt = *iq++; ls.st = *iq++; ls.zret = *iq++; ls.fused = *iq++;
         main_it = *iq++; h_valid = *iq++; ndef = *iq++; h_ident = *iq++;
         a_id = sc[29];
+        pin_scalars();
         // every wave has read the parked scalars before thread 0 may overwrite them in save(): a step that only
         // takes an objective value has no other barrier
         __syncthreads();
+    }
+
+    // the parked scalars come back as one copy per lane: pin them to scalar registers (with 1024 threads a wave has
+    // 128 VGPRs, and ~35 doubles of machine state would take 70 of them)
+    __device__ __forceinline__ void pin_scalars()
+    {
+        fnew = uni(fnew); gg = uni(gg); pp = uni(pp); phid = uni(phid); phidold = uni(phidold); a = uni(a);
+        yy_recent = uni(yy_recent); rho_recent = uni(rho_recent); a_id = uni(a_id);
+        ls.template uniformize<2>();
+        ls.fx0 = uni(ls.fx0);
+        iters = __builtin_amdgcn_readfirstlane(iters); nf = __builtin_amdgcn_readfirstlane(nf);
+        ng = __builtin_amdgcn_readfirstlane(ng); status = __builtin_amdgcn_readfirstlane(status);
+        phase = __builtin_amdgcn_readfirstlane(phase); pending = __builtin_amdgcn_readfirstlane(pending);
+        recent = __builtin_amdgcn_readfirstlane(recent); cnt = __builtin_amdgcn_readfirstlane(cnt);
+        main_it = __builtin_amdgcn_readfirstlane(main_it); h_valid = __builtin_amdgcn_readfirstlane(h_valid);
+        ndef = __builtin_amdgcn_readfirstlane(ndef); h_ident = __builtin_amdgcn_readfirstlane(h_ident);
     }
 
     __device__ __forceinline__ void finish() // x already holds the last evaluated point

@@ -155,31 +155,58 @@ template <int NW, int EPT> struct Objective<FL_OBJ_QUARTIC, NW, EPT> { // test/t
     }
 };
 
+// d, b of the diagonal quadratic: in registers (EPT <= 4), or -- 8 elements per thread, up to 256 threads -- in two
+// LDS rows that every thread reads back only where it wrote (no barrier): 32 VGPRs less for the whole solve, which
+// takes the L-BFGS kernel for n = 1024 from 181 to under 168 VGPRs = 3 waves per SIMD instead of 2
+// (profiles/r02/quad_lds_ab.txt).  The 512-thread kernels have no LDS to spare: they re-read d, b per evaluation
+// (Solver::LEAN).
+#ifndef FL_QUAD_LDS
+#define FL_QUAD_LDS 0
+#endif
 template <int NW, int EPT> struct Objective<FL_OBJ_DIAGQUAD, NW, EPT> { // f=0.5*sum(d*x*x)-sum(b*x), g=d*x-b
-    static constexpr int LDS_DOUBLES = 0;
-    double d[EPT], b[EPT];
-    __device__ __forceinline__ void init(const SolveArgs &A, int prob, double *)
+    using G = Geo<NW, EPT>;
+    static constexpr bool IN_LDS = FL_QUAD_LDS && EPT >= 8 && NW <= 4;
+    static constexpr int LDS_DOUBLES = IN_LDS ? 2 * G::NPAD : 0;
+    double d[IN_LDS ? 1 : EPT], b[IN_LDS ? 1 : EPT];
+    __device__ __forceinline__ void init(const SolveArgs &A, int prob, double *xs)
     {
-        load_user<NW, EPT>(A.d + (size_t)prob * A.n, A.n, d);
-        load_user<NW, EPT>(A.b + (size_t)prob * A.n, A.n, b);
+        if constexpr (IN_LDS) {
+            double t[EPT];
+            load_user<NW, EPT>(A.d + (size_t)prob * A.n, A.n, t);
+            store_pad<NW, EPT>(xs, t);
+            load_user<NW, EPT>(A.b + (size_t)prob * A.n, A.n, t);
+            store_pad<NW, EPT>(xs + G::NPAD, t);
+        } else {
+            load_user<NW, EPT>(A.d + (size_t)prob * A.n, A.n, d);
+            load_user<NW, EPT>(A.b + (size_t)prob * A.n, A.n, b);
+        }
     }
     __device__ __forceinline__ void eval(const double (&x)[EPT], double (&g)[EPT], double &s0, double &s1, int,
-                                         double *)
+                                         double *xs)
     {
+        double dl[EPT], bl[EPT];
+        if constexpr (IN_LDS) {
+            load_pad<NW, EPT>(xs, dl);
+            load_pad<NW, EPT>(xs + G::NPAD, bl);
+        }
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {
-            const double dx = d[k] * x[k];
-            const double t0 = dx * x[k], t1 = b[k] * x[k];
-            g[k] = dx - b[k];
+            const double dk = IN_LDS ? dl[k] : d[IN_LDS ? 0 : k], bk = IN_LDS ? bl[k] : b[IN_LDS ? 0 : k];
+            const double dx = dk * x[k];
+            const double t0 = dx * x[k], t1 = bk * x[k];
+            g[k] = dx - bk;
             s0 = (k == 0) ? t0 : s0 + t0;
             s1 = (k == 0) ? t1 : s1 + t1;
         }
     }
     __device__ __forceinline__ static double combine(double s0, double s1) { return 0.5 * s0 - s1; }
-    __device__ __forceinline__ void hess_column(int j, const double (&)[EPT], int, const double *, double (&h)[EPT])
+    __device__ __forceinline__ void hess_column(int j, const double (&)[EPT], int, const double *xs, double (&h)[EPT])
     {
+        double dl[EPT];
+        if constexpr (IN_LDS) load_pad<NW, EPT>(xs, dl);
 #pragma unroll
-        for (int k = 0; k < EPT; ++k) h[k] = (Geo<NW, EPT>::e0(k >> 1) + (k & 1) == j) ? d[k] : 0.0;
+        for (int k = 0; k < EPT; ++k)
+            h[k] = (G::e0(k >> 1) + (k & 1) == j) ? (IN_LDS ? dl[k] : d[IN_LDS ? 0 : k]) : 0.0;
     }
 };
 
@@ -324,10 +351,26 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
 #define FL_LDS_PAIRS_E2 0
 #endif
 #define FL_LDS_PAIRS(NW_, EPT_) ((EPT_) >= 8 ? FL_LDS_PAIRS_E8 : ((EPT_) == 4 ? FL_LDS_PAIRS_E4 : FL_LDS_PAIRS_E2))
-    static constexpr int LDS_PAIRS_FIT = (2560 * NW - L_G0) / (2 * NPAD);
+#ifndef FL_LDS_BUDGET
+#define FL_LDS_BUDGET 2560 // doubles of LDS per wave: 20 KiB, what 2 waves / SIMD (8 waves per CU) leave each
+#endif
+    static constexpr int LDS_PAIRS_FIT = (FL_LDS_BUDGET * NW - L_G0) / (2 * NPAD);
     static constexpr int LDS_PAIRS_WANT = (METHOD == FL_SOLVER_LBFGS && OBJ != FL_OBJ_EXTERNAL) ? FL_LDS_PAIRS(NW, EPT) : 0;
     static constexpr int LDS_PAIRS = LDS_PAIRS_WANT < LDS_PAIRS_FIT ? LDS_PAIRS_WANT : LDS_PAIRS_FIT;
     static constexpr int L_BF = L_G0 + ((NEEDS_G0 && METHOD != FL_SOLVER_BFGS) ? (LDS_PAIRS > 0 ? 2 * LDS_PAIRS * NPAD : NPAD) : 0);
+    // ... and the REG_PAIRS newest pairs stay in REGISTERS from one iteration to the next (the LDS ring then holds the
+    // LDS_PAIRS pairs after them).  The n = 1024 kernel runs 4 problems per CU either way (2 waves / SIMD by
+    // registers, 40 KiB of LDS each): what limits it is the ring traffic -- 0, 2 LDS pairs: 242, 196 ms per solve
+    // (profiles/r02/ab_pairs.txt) -- and its 181 VGPRs leave 75 of the 256 idle.
+#ifndef FL_REG_PAIRS_E8
+#define FL_REG_PAIRS_E8 1 // measured (profiles/r02/ab_pairs.txt): 0, 1, 2 register pairs: 198, 176, 179 ms per solve
+#endif
+#ifndef FL_REG_PAIRS_E4
+#define FL_REG_PAIRS_E4 0
+#endif
+    static constexpr int REG_PAIRS = (METHOD == FL_SOLVER_LBFGS && OBJ != FL_OBJ_EXTERNAL && !AUG)
+                                         ? ((EPT >= 8 && NW <= 2) ? FL_REG_PAIRS_E8 : (EPT == 4 ? FL_REG_PAIRS_E4 : 0)) : 0;
+    static_assert(REG_PAIRS >= 0 && REG_PAIRS <= 2, "0, 1 or 2 register pairs");
     // Newton: one row buffer for the Cholesky kernels (BFGS reuses its broadcast arrays)
     static constexpr int L_DEF = L_BF + (METHOD == FL_SOLVER_BFGS ? 3 * NPAD : (METHOD == FL_SOLVER_NEWTON ? NPAD : 0));
     // BFGS for n > 1024, fused kernels: the rank-2 updates are DEFERRED -- H is left alone for BF_DEFER iterations
@@ -352,6 +395,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
     int iters, nf, ng, status, phase, pending;
     int recent, cnt;    // L-BFGS ring
     int lrec;           // slot of the newest pair in the LDS ring (LDS_PAIRS > 0)
+    double rs_[REG_PAIRS > 0 ? REG_PAIRS : 1][EPT], ry_[REG_PAIRS > 0 ? REG_PAIRS : 1][EPT]; // register pairs, newest first
     int main_it, h_valid; // BFGS / Newton: main-loop iteration counter (iIteration), inverse Hessian initialised
     int ndef, h_ident;    // deferred BFGS: pending updates; H is still the implicit a_id * I of the first step
     double a_id;
@@ -950,13 +994,36 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
             sv[k] = x[k] - x0[k];
             yv[k] = g[k] - g0[k];
         }
-        constexpr int K = LDS_PAIRS;
-        if constexpr (K > 0) {
+        constexpr int K = LDS_PAIRS, RP = REG_PAIRS;
+        if constexpr (RP > 0) {
+            // the pair that leaves the registers joins the LDS ring (g_old was parked in that slot's y row and is
+            // already in g0), the others move up, the new pair becomes the newest
+            if (cnt > RP) { // (cnt counts the new pair: there were at least RP before it)
+                if constexpr (K > 0) {
+                    lrec = (lrec + 1 == K) ? 0 : lrec + 1;
+                    store_pad<NW, EPT>(lds_pair(lrec), rs_[RP - 1]);
+                    store_pad<NW, EPT>(lds_pair(lrec) + NPAD, ry_[RP - 1]);
+                }
+            }
+#pragma unroll
+            for (int r_ = RP - 1; r_ >= 1; --r_) {
+#pragma unroll
+                for (int k = 0; k < EPT; ++k) {
+                    rs_[r_][k] = rs_[r_ - 1][k];
+                    ry_[r_][k] = ry_[r_ - 1][k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+                rs_[0][k] = sv[k];
+                ry_[0][k] = yv[k];
+            }
+        } else if constexpr (K > 0) {
             lrec = (lrec + 1 == K) ? 0 : lrec + 1; // g_old was parked in this slot's y row (already in g0)
             store_pad<NW, EPT>(lds_pair(lrec), sv);
             store_pad<NW, EPT>(lds_pair(lrec) + NPAD, yv);
         }
-        if (K == 0 || mem > K) { // a ring that fits in LDS never touches HBM
+        if (K + RP == 0 || mem > K + RP) { // a ring that fits on the chip never touches HBM
             store_pad<NW, EPT>(hist + (size_t)(2 * recent) * NPAD, sv);
             store_pad<NW, EPT>(hist + (size_t)(2 * recent + 1) * NPAD, yv);
         }
@@ -977,9 +1044,9 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
             int s = recent - j;
             return s < 0 ? s + mem : s;
         };
-        auto fetch = [&](int j, double (&s_)[EPT], double (&y_)[EPT]) {
-            if (K > 0 && j < K) { // one of the K newest: from the LDS ring (separate branches keep ds_read / global_load)
-                const int ls = lrec - j;
+        auto fetch = [&](int j, double (&s_)[EPT], double (&y_)[EPT]) { // j >= RP: the pairs behind the register pairs
+            if (K > 0 && j < RP + K) { // in the LDS ring (separate branches keep ds_read / global_load apart)
+                const int ls = lrec - (j - RP);
                 const double *row = lds_pair(ls < 0 ? ls + K : ls);
                 load_pad<NW, EPT>(row, s_);
                 load_pad<NW, EPT>(row + NPAD, y_);
@@ -1007,12 +1074,18 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
 #pragma unroll
             for (int k = 0; k < EPT; ++k) p[k] = p[k] + co * s_[k];
         };
-        // Row buffers by parity of j (j-th newest pair): odd j -> B, even j -> A; on the way down j = 0 is the
-        // pair just formed in registers (sv, yv).  The oldest pair is used twice in a row (last step down, first
-        // step up) and is not fetched again; every other row is in flight one step ahead of its use.
-        if (cnt > 1) fetch(1, sB, yB);
+        // Row buffers: the pairs that have to be fetched alternate between B and A, starting with B at j = J0 (the
+        // first pair behind the ones the way down has in registers: the new pair sv, yv and the register pairs).  The
+        // oldest pair is used twice in a row (last step down, first step up) and is not fetched again; every other
+        // row is in flight one step ahead of its use.  On the way up the pairs j >= L come through the buffers
+        // (j = 0 too when no pair is kept in registers), the register pairs last.
+        constexpr int J0 = RP > 1 ? RP : 1, L = RP;
+        if (cnt > J0) fetch(J0, sB, yB);
         down(0, sv, yv);
-        for (int j = 1; j < cnt; j += 2) {
+        if constexpr (RP == 2) {
+            if (cnt > 1) down(1, rs_[1], ry_[1]);
+        }
+        for (int j = J0; j < cnt; j += 2) {
             if (j + 1 < cnt) fetch(j + 1, sA, yA);
             down(j, sB, yB);
             if (j + 1 < cnt) {
@@ -1023,21 +1096,25 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
 #pragma unroll
         for (int k = 0; k < EPT; ++k) p[k] = p[k] / rho_recent / yy_recent; // p=p/rho(recent)/(y.y)
         __syncthreads(); // alpha_s written by thread 0 is visible (NW == 1 has no reduction barrier)
-        // (holding the newest pair in registers across the whole recursion as well was measured: the kernel
-        //  goes from 112 to 252 VGPRs, one wave per SIMD, 18.4 instead of 27.8 M it/s -- so it is re-read here)
         int j = cnt - 1;
-        if (cnt == 1) fetch(0, sA, yA);
-        if ((j & 1) == 0) { // even top: resident in A
-            if (j - 1 >= 0) fetch(j - 1, sB, yB);
+        if (RP == 0 && cnt == 1) fetch(0, sA, yA);
+        if (j >= L && (((j - J0) & 1) != 0)) { // the top pair waits in A
+            if (j - 1 >= L) fetch(j - 1, sB, yB);
             upw(j, sA, yA);
             --j;
         }
-        for (; j >= 1; j -= 2) { // j odd: resident / prefetched in B
-            fetch(j - 1, sA, yA);
+        for (; j >= L; j -= 2) { // j: resident / prefetched in B
+            if (j - 1 >= L) fetch(j - 1, sA, yA);
             upw(j, sB, yB);
-            if (j - 2 >= 0) fetch(j - 2, sB, yB);
-            upw(j - 1, sA, yA);
+            if (j - 1 >= L) {
+                if (j - 2 >= L) fetch(j - 2, sB, yB);
+                upw(j - 1, sA, yA);
+            }
         }
+        if constexpr (RP == 2) {
+            if (cnt > 1) upw(1, rs_[1], ry_[1]);
+        }
+        if constexpr (RP >= 1) upw(0, rs_[0], ry_[0]);
 #pragma unroll
         for (int k = 0; k < EPT; ++k) p[k] = -p[k];
         r[0] = dot_part<EPT>(g, p);
@@ -1375,6 +1452,18 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
         iters = *iq++; nf = *iq++; ng = *iq++; status = *iq++; phase = *iq++; pending = *iq++;
         recent = *iq++; cnt = *iq++; ls.st = *iq++; ls.zret = *iq++; ls.fused = *iq++;
         main_it = *iq++; h_valid = *iq++; hess_stage = *iq++;
+        if constexpr (LEAN) { // the parked scalars arrive as one copy per lane: pin them to scalar registers
+            fnew = uni(fnew); gg = uni(gg); pp = uni(pp); phid = uni(phid); phidold = uni(phidold); a = uni(a);
+            yy_recent = uni(yy_recent); rho_recent = uni(rho_recent);
+            fv_c = uni(fv_c); pv_c = uni(pv_c);
+            ls.template uniformize<2>();
+            iters = __builtin_amdgcn_readfirstlane(iters); nf = __builtin_amdgcn_readfirstlane(nf);
+            ng = __builtin_amdgcn_readfirstlane(ng); status = __builtin_amdgcn_readfirstlane(status);
+            phase = __builtin_amdgcn_readfirstlane(phase); pending = __builtin_amdgcn_readfirstlane(pending);
+            recent = __builtin_amdgcn_readfirstlane(recent); cnt = __builtin_amdgcn_readfirstlane(cnt);
+            main_it = __builtin_amdgcn_readfirstlane(main_it); h_valid = __builtin_amdgcn_readfirstlane(h_valid);
+            hess_stage = __builtin_amdgcn_readfirstlane(hess_stage);
+        }
         // every wave has read the parked scalars before thread 0 may overwrite them in save(): a step that only
         // takes an objective value has no other barrier
         __syncthreads();
