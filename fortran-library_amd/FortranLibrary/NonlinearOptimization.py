@@ -315,6 +315,13 @@ def minimize_rci(solver, x, fun, options=None, max_steps=10000000, check_every=8
     return out
 
 
+def lbfgs_onchip_pairs(objective, n):
+    """pairs of the (s, y) ring the fused L-BFGS kernel keeps in registers / LDS for this objective and dimension"""
+    FL.fl_lbfgs_onchip_pairs.restype = C.c_int
+    FL.fl_lbfgs_onchip_pairs.argtypes = [C.c_int, C.c_int]
+    return int(FL.fl_lbfgs_onchip_pairs(int(objective), int(n)))
+
+
 def two_loop(hist, rho, g, p, memory, recent):
     """Stand-alone batched two-loop recursion (Before(), NO.f90:586-608): p = -H g."""
     B, n = g.shape

@@ -280,6 +280,17 @@ static int solve(int method, int objective, int batch, int n, double *x, const d
     return launch_status(e);
 }
 
+// how many of the newest (s, y) pairs the fused L-BFGS kernel for this objective and dimension keeps on the chip
+// (registers + LDS ring): the rest of the ring streams from HBM twice per iteration
+template <int NW, int EPT> static int onchip_pairs_o(int obj)
+{
+    switch (obj) {
+    case FL_OBJ_QUARTIC: { using S = Solver<NW, EPT, FL_OBJ_QUARTIC, FL_SOLVER_LBFGS, 0>; return S::LDS_PAIRS + S::REG_PAIRS; }
+    case FL_OBJ_ROSENBROCK: { using S = Solver<NW, EPT, FL_OBJ_ROSENBROCK, FL_SOLVER_LBFGS, 0>; return S::LDS_PAIRS + S::REG_PAIRS; }
+    default: { using S = Solver<NW, EPT, FL_OBJ_DIAGQUAD, FL_SOLVER_LBFGS, 0>; return S::LDS_PAIRS + S::REG_PAIRS; }
+    }
+}
+
 } // namespace fl
 
 extern "C" {
@@ -327,6 +338,18 @@ int fl_newton_raphson_batched(int objective, int batch, int n, double *x_dev, co
 {
     return fl::solve(FL_SOLVER_NEWTON, objective, batch, n, x_dev, d_dev, b_dev, opt, workspace_dev, workspace_bytes,
                      f_dev, gg_dev, iters_dev, status_dev, nf_dev, ng_dev, nullptr, stream);
+}
+
+int fl_lbfgs_onchip_pairs(int objective, int n)
+{
+    fl::GeoSel g;
+    if (!fl::select_geometry(n, g)) return 0; // vectors-in-HBM path: nothing of the ring stays on the chip
+    if (g.nw == 1 && g.ept == 2) return fl::onchip_pairs_o<1, 2>(objective);
+    if (g.nw == 1 && g.ept == 4) return fl::onchip_pairs_o<1, 4>(objective);
+    if (g.nw == 2 && g.ept == 4) return fl::onchip_pairs_o<2, 4>(objective);
+    if (g.nw == 2 && g.ept == 8) return fl::onchip_pairs_o<2, 8>(objective);
+    if (g.nw == 4 && g.ept == 8) return fl::onchip_pairs_o<4, 8>(objective);
+    return fl::onchip_pairs_o<8, 8>(objective);
 }
 
 int fl_reduction_geometry(int n, int *threads, int *ept)

@@ -1,4 +1,5 @@
-"""world_size-2 gloo test of the multi-GPU path (runs on CPU): shard -> solve -> gather to rank 0.
+"""world_size-2 gloo test of the multi-GPU path (runs on CPU): shard -> solve -> gather to rank 0
+(contiguous and interleaved assignment, ragged shards padded inside the gatherer, buffers reused).
 
 The per-rank "solve" is the CPU oracle standing in for the HIP kernel (this is a test of the sharding and
 of the single gather, the only communication of the job); rank 0 must end up with exactly the results of
@@ -22,7 +23,7 @@ def _problem(B, n):
     return d, b
 
 
-def _worker(rank, world, port, B, n, ret):
+def _worker(rank, world, port, B, n, ret, interleaved):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     sys.path.insert(0, os.path.join(ROOT, "fortran-library_amd", "FortranLibrary"))
     import oracle_lib as O
@@ -31,24 +32,27 @@ def _worker(rank, world, port, B, n, ret):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     d, b = _problem(B, n)
-    lo, hi = D.shard_bounds(B, rank, world)
-    r = O.solve_batch(O.LBFGS, O.DIAGQUAD, np.zeros((hi - lo, n)), d=d[lo:hi], b=b[lo:hi],
+    idx = D.shard_indices(B, rank, world, interleaved).numpy()
+    assert len(idx) == D.shard_size(B, rank, world, interleaved)
+    r = O.solve_batch(O.LBFGS, O.DIAGQUAD, np.zeros((len(idx), n)), d=d[idx], b=b[idx],
                       opts=O.defaults(precision=1e-6), nthreads=1)
-    # pad the last shard so that every rank contributes the same shape (gather needs equal sizes)
-    per = -(-B // world)
-    def pad(a):
-        t = torch.from_numpy(np.ascontiguousarray(a))
-        if t.shape[0] < per:
-            t = torch.cat([t, torch.zeros((per - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype)])
-        return t
-    res = D.gather_results({"x": pad(r["x"]), "f": pad(r["f"]), "iters": pad(r["iters"]), "status": pad(r["status"])})
+    # ragged shards go in as they are: the gatherer pads to ceil(B / world) rows and trims on rank 0
+    G = D.Gatherer(B, {"x": ((n,), torch.float64), "f": ((), torch.float64), "iters": ((), torch.int32),
+                       "status": ((), torch.int32)}, torch.device("cpu"), dst=0, interleaved=interleaved)
+    mine = {k: torch.from_numpy(np.ascontiguousarray(r[k])) for k in ("x", "f", "iters", "status")}
+    for _ in range(2):  # the buffers are reused from step to step
+        res = G.gather(mine)
     dist.barrier()
     if rank == 0:
-        ret["x"] = res["x"][:B].numpy()
-        ret["f"] = res["f"][:B].numpy()
-        ret["iters"] = res["iters"][:B].numpy()
+        assert res["x"].shape == (B, n)
+        ret["x"] = res["x"].numpy().copy()
+        ret["f"] = res["f"].numpy().copy()
+        ret["iters"] = res["iters"].numpy().copy()
+        one = D.gather_results(mine, batch=B, interleaved=interleaved)  # the one-shot form gives the same
+        assert torch.equal(one["x"], res["x"]) and torch.equal(one["iters"], res["iters"])
     else:
         assert res is None
+        assert D.gather_results(mine, batch=B, interleaved=interleaved) is None
     dist.destroy_process_group()
 
 
@@ -63,13 +67,29 @@ def test_shard_bounds_cover_batch_exactly():
             assert max(h - l for l, h in cuts) == -(-B // w)
 
 
-def test_two_rank_gloo_shard_solve_gather():
+def test_shard_indices_partition_the_batch():
+    sys.path.insert(0, os.path.join(ROOT, "fortran-library_amd", "FortranLibrary"))
+    import distributed as D
+    for B in (1, 7, 8, 1000):
+        for w in (1, 2, 3, 8):
+            for inter in (False, True):
+                parts = [D.shard_indices(B, r, w, inter) for r in range(w)]
+                assert sorted(torch.cat(parts).tolist()) == list(range(B))
+                assert [len(p_) for p_ in parts] == [D.shard_size(B, r, w, inter) for r in range(w)]
+                assert max(len(p_) for p_ in parts) <= -(-B // w)
+
+
+import pytest
+
+
+@pytest.mark.parametrize("interleaved", [False, True])
+def test_two_rank_gloo_shard_solve_gather(interleaved):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     B, n, world = 7, 64, 2  # ragged: ranks own 4 and 3 problems
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_worker, args=(world, 29533, B, n, ret), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, 29533 + int(interleaved), B, n, ret, interleaved), nprocs=world, join=True)
         d, b = _problem(B, n)
         ref = O.solve_batch(O.LBFGS, O.DIAGQUAD, np.zeros((B, n)), d=d, b=b, opts=O.defaults(precision=1e-6), nthreads=1)
         assert np.array_equal(ret["x"], ref["x"])

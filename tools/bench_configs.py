@@ -26,8 +26,14 @@ from bench import host_cores, cpu_model, SEED, HBM_PEAK_GBS
 dev = torch.device("cuda:0")
 
 
+REPS = None  # --reps: fixed number of timed launches (1 for the PMC passes of tools/profile.sh; no warm-up launch then)
+
+
 def timed(fn, reps=2):
-    fn()
+    if REPS is not None:
+        reps = REPS
+    if REPS is None:
+        fn()
     torch.cuda.synchronize()
     ms = []
     for _ in range(reps):
@@ -42,6 +48,11 @@ def timed(fn, reps=2):
 
 def cpu_rate(call, S0, seconds, cores):
     """iterations/s of the oracle: pilot on S0 problems, then a sample sized for `seconds` of wall time"""
+    if seconds <= 0:  # profiling runs: no CPU leg
+        class _Nothing(dict):
+            def __getitem__(self, k):
+                return np.full(1 << 20, np.nan)
+        return float("nan"), 0, 0.0, _Nothing()
     t = time.perf_counter()
     call(S0)
     pilot = max(time.perf_counter() - t, 1e-3)
@@ -64,9 +75,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("configs", nargs="*", default=["c2", "c3", "c4", "c5"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--reps", type=int, default=None, help="timed launches per configuration (profiling: 1, no warm-up)")
     ap.add_argument("--c4-batch", type=int, default=1024)
     ap.add_argument("--c4-iterations", type=int, default=20)
     args = ap.parse_args()
+    global REPS
+    REPS = args.reps
     cores = host_cores()
     host = f"{cores} cores of {cpu_model()}"
 
@@ -153,8 +167,11 @@ def main():
         oo = O.defaults(precision=1e-12, maxit=K - 1, exact_step=0)
         dh, bh = d[:Bc].cpu().numpy(), b[:Bc].cpu().numpy()
         t = time.perf_counter()
-        ref = O.solve_batch(O.BFGS, O.DIAGQUAD, np.zeros((Bc, n)), d=dh, b=bh, opts=oo, bfgs_form=1, nthreads=cores)
-        dt = time.perf_counter() - t
+        if args.cpu_seconds > 0:
+            ref = O.solve_batch(O.BFGS, O.DIAGQUAD, np.zeros((Bc, n)), d=dh, b=bh, opts=oo, bfgs_form=1, nthreads=cores)
+        else:  # profiling runs: no CPU leg
+            ref = {"iters": np.full(Bc, np.nan), "f": np.full(Bc, np.nan)}
+        dt = max(time.perf_counter() - t, 1e-9)
         print(json.dumps({"config": f"C4 dense BFGS (ExactStep=0), diagonal quadratics n=4096 kappa in [10,100], batch {B}, "
                                     f"fixed {K} iterations", "ms": ms, "iterations_per_s": float(it.sum()) / ms * 1e3,
                           "iterations": int(it.sum()),
