@@ -26,9 +26,11 @@ HIP events on the launch stream):
                 profiles/traffic.json only while its record is of the same kernel sources and workload;
   * achieved  = traffic / kernel time (when there is no valid record: the model below / kernel time),
                 frac = achieved / 8 TB/s -- a bound that binds: <= 1 by construction;
-  * model     = the minimum HBM bytes of the shipped kernel: with C pairs of the ring on the chip
-                (fl_lbfgs_onchip_pairs) an iteration fetches max(0,2(cnt-C)) + max(0,2(cnt-C-1)) rows and
-                stores 2; traffic_over_model > 1 is re-fetching, < 1 would be a wrong model;
+  * model     = the bytes the shipped kernel asks the L2 for: with C pairs of the ring on the chip
+                (fl_lbfgs_onchip_pairs) an iteration loads max(0,2(cnt-C)) + max(0,2(cnt-C-1)) rows and
+                stores 2.  traffic_over_model is what of it crossed to the memory side: 1 - (L2 hits), the rows
+                around the turn-around of the recursion being re-read within a few microseconds; > 1 would be
+                re-fetching;
   * algorithmic_bw = SURVEY.md 8(d)'s streaming figure, (4*cnt+2)*8n per iteration and problem,
                 / kernel time: what a kernel WITHOUT on-chip reuse would have to move at this speed.  It may
                 exceed the HBM peak -- the rows served from registers / LDS never cross the pins -- and is
@@ -314,10 +316,12 @@ def main():
                      "onchip_pairs": C_on,
                      "algorithmic_bytes_per_launch": algo_bytes, "algorithmic_bw": algo_bytes / (kern_ms * 1e-3) / 1e9,
                      "trial_phase": trial_phase,
-                     "note": "frac = bytes that crossed the L2's memory side (PMC) / kernel time / 8 TB/s; model = "
-                             "minimum HBM bytes of the shipped kernel (C on-chip pairs); algorithmic_bw = SURVEY 8d "
-                             "streaming figure (4*cnt+2)*8n per iteration, credited for rows served on chip, so it may "
-                             "exceed the peak and is not a utilisation"},
+                     "l2_hit_rate": (pmc["TCC_HIT_sum"] / (pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]))
+                     if pmc and pmc.get("TCC_HIT_sum") else None,
+                     "note": "frac = bytes that crossed the L2's memory side (PMC: Infinity-Cache hits included) / kernel "
+                             "time / 8 TB/s; model = bytes the kernel requests from L2 (ring rows not kept on the chip); "
+                             "algorithmic_bw = SURVEY 8d streaming figure (4*cnt+2)*8n per iteration, credited for rows "
+                             "served on chip, so it may exceed the peak and is not a utilisation"},
     }
 
     # ---- stand-alone two-loop recursion on the solver's own final history

@@ -1,47 +1,20 @@
 // fl_linalg.cpp -- the LinearAlgebra entry points the reference's C++ header binds next to the optimisers
-// (cpp/FortranLibrary.hpp:48-63): My_dgemm / My_dgemm_T (LinearAlgebra.f90:182-196: plain dgemm calls) and My_dsyev
-// (879-887: dsyev 'L').  The reference hands these to MKL; here they are handed to the vendor libraries of the ROCm
-// stack -- rocBLAS dgemm, rocSOLVER dsyev -- on the GPU: host arrays in, host arrays out, like the reference.
-// Plain library calls (no kernel of this repository is involved); same results to rounding, eigenvectors up to sign.
-// The libraries are opened on first use (dlopen), so libFL.so itself does not depend on them.
-#include <dlfcn.h>
+// (cpp/FortranLibrary.hpp:48-63): My_dgemm / My_dgemm_T (LinearAlgebra.f90:182-196: dgemm calls) and My_dsyev
+// (879-887: dsyev 'L') -- host arrays in, host arrays out, like the reference -- and the TrustRegion replacement.
+// The reference hands the three to MKL; here they run on kernels of this library (csrc/fl_blas_kernels.hip: an f64-MFMA
+// DGEMM and a cyclic Jacobi eigensolver).  No vendor BLAS / LAPACK is opened.
 #include <hip/hip_runtime.h>
-#include <rocblas/rocblas.h>
-#include <rocsolver/rocsolver.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
-#include <mutex>
+#include <numeric>
 #include <vector>
 
 #include "../../include/fl_nlopt.h"
 
 namespace {
-
-struct Vendor {
-    void *blas = nullptr, *solver = nullptr;
-    rocblas_handle handle = nullptr;
-    decltype(&rocblas_create_handle) create = nullptr;
-    decltype(&rocblas_dgemm) dgemm = nullptr;
-    decltype(&rocsolver_dsyev) dsyev = nullptr;
-    bool ok = false;
-};
-Vendor &vendor()
-{
-    static Vendor v;
-    static std::once_flag once;
-    std::call_once(once, [] {
-        v.blas = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-        v.solver = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!v.blas || !v.solver) return;
-        v.create = reinterpret_cast<decltype(v.create)>(dlsym(v.blas, "rocblas_create_handle"));
-        v.dgemm = reinterpret_cast<decltype(v.dgemm)>(dlsym(v.blas, "rocblas_dgemm"));
-        v.dsyev = reinterpret_cast<decltype(v.dsyev)>(dlsym(v.solver, "rocsolver_dsyev"));
-        v.ok = v.create && v.dgemm && v.dsyev && v.create(&v.handle) == rocblas_status_success;
-    });
-    return v;
-}
 
 struct DeviceBuffer {
     void *p = nullptr;
@@ -53,20 +26,18 @@ struct DeviceBuffer {
 // C(M,N) = op(A) B, column-major; transA: A is K x M
 void gemm(bool transA, const double *A, const double *B, double *C, int M, int K, int N)
 {
-    Vendor &v = vendor();
     int ndev = 0;
-    if (!v.ok || hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
-        std::fprintf(stderr, "FortranLibrary(MI355X) My_dgemm: no HIP device or rocBLAS; C is unchanged\n");
+    if (M <= 0 || N <= 0 || K <= 0) return;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        std::fprintf(stderr, "FortranLibrary(MI355X) My_dgemm: no HIP device; C is unchanged\n");
         return;
     }
     const size_t a = sizeof(double) * (size_t)M * K, b = sizeof(double) * (size_t)K * N, c = sizeof(double) * (size_t)M * N;
     DeviceBuffer Ad(a), Bd(b), Cd(c);
-    const double one = 1.0, zero = 0.0;
     bool ok = Ad.p && Bd.p && Cd.p && hipMemcpy(Ad.p, A, a, hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(Bd.p, B, b, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && v.dgemm(v.handle, transA ? rocblas_operation_transpose : rocblas_operation_none, rocblas_operation_none, M, N,
-                       K, &one, Ad.as<double>(), transA ? K : M, Bd.as<double>(), K, &zero, Cd.as<double>(), M) ==
-                   rocblas_status_success;
+    ok = ok && fl_dgemm(transA ? 1 : 0, M, K, N, Ad.as<double>(), transA ? K : M, Bd.as<double>(), K, Cd.as<double>(), M,
+                        nullptr) == FL_OK;
     ok = ok && hipMemcpy(C, Cd.p, c, hipMemcpyDeviceToHost) == hipSuccess;
     if (!ok) std::fprintf(stderr, "FortranLibrary(MI355X) My_dgemm: device error; C is undefined\n");
 }
@@ -89,22 +60,37 @@ void __linearalgebra_MOD_my_dgemm_t(const double *A, const double *B, double *C,
 // (LinearAlgebra.f90:879-887: dsyev(jobtype,'L',...); "A will be overwritten even for 'N' job")
 void __linearalgebra_MOD_my_dsyev(const char *jobtype, double *A, double *eigval, const int *N, int /*len_jobtype*/)
 {
-    Vendor &v = vendor();
     const int n = *N;
     int ndev = 0;
-    if (!v.ok || hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
-        std::fprintf(stderr, "FortranLibrary(MI355X) My_dsyev: no HIP device or rocSOLVER; A is unchanged\n");
+    if (n <= 0) return;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        std::fprintf(stderr, "FortranLibrary(MI355X) My_dsyev: no HIP device; A is unchanged\n");
         return;
     }
-    const size_t a = sizeof(double) * (size_t)n * n;
-    DeviceBuffer Ad(a), Dd(sizeof(double) * n), Ed(sizeof(double) * n), info(sizeof(rocblas_int));
+    const size_t a = sizeof(double) * (size_t)n * n, wsb = fl_dsyev_workspace_bytes(n);
+    DeviceBuffer Ad(a), Wd(sizeof(double) * n), ws(wsb);
     const bool vec = jobtype && (*jobtype == 'V' || *jobtype == 'v');
-    bool ok = Ad.p && Dd.p && Ed.p && info.p && hipMemcpy(Ad.p, A, a, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && v.dsyev(v.handle, vec ? rocblas_evect_original : rocblas_evect_none, rocblas_fill_lower, n, Ad.as<double>(), n,
-                       Dd.as<double>(), Ed.as<double>(), info.as<rocblas_int>()) == rocblas_status_success;
-    ok = ok && hipMemcpy(eigval, Dd.p, sizeof(double) * n, hipMemcpyDeviceToHost) == hipSuccess &&
-         hipMemcpy(A, Ad.p, a, hipMemcpyDeviceToHost) == hipSuccess;
-    if (!ok) std::fprintf(stderr, "FortranLibrary(MI355X) My_dsyev: device error; A, eigval are undefined\n");
+    int sweeps = 0;
+    bool ok = Ad.p && Wd.p && ws.p && hipMemcpy(Ad.p, A, a, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && fl_dsyev_jacobi(vec ? 'V' : 'N', n, Ad.as<double>(), n, Wd.as<double>(), ws.p, wsb, 60, &sweeps, nullptr) == FL_OK;
+    std::vector<double> w(n), V;
+    ok = ok && hipMemcpy(w.data(), Wd.p, sizeof(double) * n, hipMemcpyDeviceToHost) == hipSuccess;
+    if (ok && vec) {
+        V.resize((size_t)n * n);
+        ok = hipMemcpy(V.data(), ws.as<double>() + (size_t)n * n, a, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    if (!ok) {
+        std::fprintf(stderr, "FortranLibrary(MI355X) My_dsyev: device error; A, eigval are undefined\n");
+        return;
+    }
+    if (sweeps < 0) std::fprintf(stderr, "FortranLibrary(MI355X) My_dsyev: Jacobi sweeps exhausted before convergence\n");
+    // eigenvalues in ascending order, eigenvectors follow (dsyev's contract, LinearAlgebra.f90:877)
+    std::vector<int> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return w[x] < w[y]; });
+    for (int k = 0; k < n; ++k) eigval[k] = w[order[k]];
+    if (vec)
+        for (int k = 0; k < n; ++k) std::copy(V.begin() + (size_t)order[k] * n, V.begin() + (size_t)(order[k] + 1) * n, A + (size_t)k * n);
 }
 // the ifort manglings (FortranLibrary.hpp:27-43)
 void linearalgebra_mp_my_dgemm_(const double *A, const double *B, double *C, const int *M, const int *K, const int *N)
@@ -128,7 +114,7 @@ void linearalgebra_mp_my_dsyev_(const char *jobtype, double *A, double *eigval, 
 // The reference is a wrapper of MKL's closed RCI solver dtrnlsp -- there is no algorithm in the reference to restate
 // (SURVEY.md 8f.4), so this is an own Levenberg-Marquardt iteration with Nielsen's damping update behind the same
 // interface and stopping options: PARITY UNPINNED by construction (same stationary points, different path).
-// Callbacks on the host; J^T J, J^T f' through rocBLAS and the damped normal equations through fl_dposv_batched on
+// Callbacks on the host; J^T J, J^T f' through fl_dgemm and the damped normal equations through fl_dposv_batched on
 // the GPU.  Bounds (low, up) are honoured by projecting every trial point.
 typedef void (*res_cb)(double *, const double *, const int &, const int &);
 typedef int (*jac_cb)(double *, const double *, const int &, const int &);

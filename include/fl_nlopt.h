@@ -175,6 +175,20 @@ int fl_dpotri_batched(int batch, int n, double *A_dev, double *work_dev, int32_t
  *                        Elimination with partial pivoting; n <= 4096. */
 int fl_dsysv_batched(int batch, int n, double *A_dev, double *b_dev, int32_t *info_dev, void *stream);
 
+/* LinearAlgebra.f90's My_dgemm / My_dgemm_T (182-196; cpp/FortranLibrary.hpp:50-63) on device pointers:
+ * C(M,N) = op(A) B, column-major, alpha = 1, beta = 0; transA = 0: A is M x K (lda >= M), transA = 1: A is K x M
+ * (lda >= K); B is K x N (ldb >= K); C ldc >= M.  f64 matrix cores (v_mfma_f64_16x16x4_f64), 128 x 128 tiles. */
+int fl_dgemm(int transA, int M, int K, int N, const double *A_dev, int lda, const double *B_dev, int ldb, double *C_dev,
+             int ldc, void *stream);
+/* My_dsyev (LinearAlgebra.f90:879-887) by cyclic two-sided Jacobi: A_dev n x n column-major (lda = n), lower triangle
+ * referenced, destroyed.  w_dev[n] <- the eigenvalues UNSORTED; jobz = 'V': the matching normalised eigenvectors are
+ * the columns of the n x n matrix at (double *)workspace_dev + n*n.  *sweeps_out (host, may be NULL): sweeps used,
+ * negative if max_sweeps were not enough.  The call synchronises the stream once per sweep (convergence test).
+ * The legacy symbol __linearalgebra_MOD_my_dsyev sorts ascending and copies back to the host arrays. */
+size_t fl_dsyev_workspace_bytes(int n);
+int fl_dsyev_jacobi(char jobz, int n, double *A_dev, int lda, double *w_dev, void *workspace_dev, size_t workspace_bytes,
+                    int max_sweeps, int *sweeps_out, void *stream);
+
 /* The BFGS inverse-Hessian update AS THE REFERENCE WRITES IT: U = I - rho y s^T, rho = 1/(y.s),
  * H <- matmul(transpose(U), matmul(H, U)) + rho s s^T  (NO.f90:958-962; LinearAlgebra.f90:105-114
  * vector_direct_product) -- two dense n^3 products on the f64 matrix cores (v_mfma_f64_16x16x4_f64),

@@ -52,7 +52,7 @@ def cpu_rate(call, S0, seconds, cores):
         class _Nothing(dict):
             def __getitem__(self, k):
                 return np.full(1 << 20, np.nan)
-        return float("nan"), 0, 0.0, _Nothing()
+        return float("nan"), 1, 0.0, _Nothing()
     t = time.perf_counter()
     call(S0)
     pilot = max(time.perf_counter() - t, 1e-3)

@@ -73,7 +73,7 @@ def main():
     os.makedirs(dst, exist_ok=True)
     src = []
     for f in {v[2] for v in cs.values()}:
-        name = f"{tag}_pmc_" + os.path.basename(os.path.dirname(os.path.dirname(os.path.dirname(f)))).replace("pmc_", "") + ".csv"
+        name = f"{tag}_pmc_" + os.path.basename(os.path.dirname(os.path.dirname(f))).replace("pmc_", "") + ".csv"
         # keep only the rows of the kernel in question (the files hold every dispatch of the process)
         with open(f) as fi, open(os.path.join(dst, name), "w", newline="") as fo:
             rd = csv.DictReader(fi)
