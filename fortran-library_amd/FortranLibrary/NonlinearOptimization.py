@@ -315,6 +315,27 @@ def minimize_rci(solver, x, fun, options=None, max_steps=10000000, check_every=8
     return out
 
 
+def dgemm(A, B, transA=False):
+    """My_dgemm / My_dgemm_T on device tensors.  Column-major operands given as torch tensors of the TRANSPOSED shape
+    (a row of the tensor = a column of the matrix): A [K, M] holds the M x K matrix (transA: A [M, K] holds the K x M
+    one), B [N, K] holds K x N.  Returns C as a tensor [N, M] = the M x N product, column-major."""
+    import torch
+    FL.fl_dgemm.restype = C.c_int
+    FL.fl_dgemm.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                            C.c_int, C.c_void_p]
+    if transA:
+        M, K = A.shape
+        lda = K
+    else:
+        K, M = A.shape
+        lda = M
+    N = B.shape[0]
+    assert B.shape[1] == K
+    out = torch.empty(N, M, dtype=torch.float64, device=A.device)
+    _check(FL.fl_dgemm(1 if transA else 0, M, K, N, _ptr(A), lda, _ptr(B), K, _ptr(out), M, _stream()), "fl_dgemm")
+    return out
+
+
 def lbfgs_onchip_pairs(objective, n):
     """pairs of the (s, y) ring the fused L-BFGS kernel keeps in registers / LDS for this objective and dimension"""
     FL.fl_lbfgs_onchip_pairs.restype = C.c_int

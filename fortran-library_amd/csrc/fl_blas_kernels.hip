@@ -29,17 +29,21 @@
 namespace fl {
 
 using f64x4 = __attribute__((ext_vector_type(4))) double;
-constexpr int DBM = 128, DBN = 128, DBK = 16, DPAD = 16; // DPAD: rows of the LDS image 32 banks apart
+constexpr int DBK = 16, DPAD = 16; // DPAD: rows of the LDS image 32 banks apart
 
 // X is "index-contiguous" (element (idx, k) at idx + k*ld): A for 'N'.  Thread t stages 8 doubles of row kk.
 // X is "k-contiguous"     (element (idx, k) at k + idx*ld): A for 'T', and B.  Thread t stages k = 8*(t&1).. of idx t>>1.
-template <int WGM, int WGN>
+// BT x BT tile per workgroup of WGM x WGN waves = BT*4 threads: 128 (2 x 4 waves, 8 accumulator tiles per wave) for
+// large problems, 64 (2 x 2 waves, 4 tiles) while 128-tiles would leave CUs idle (n = 1024: 64 tiles for 256 CUs).
+template <int BT, int WGM, int WGN>
 __global__ __launch_bounds__(WGM * WGN * 64) void dgemm_kernel(int transA, int M, int K, int N, const double *A, int lda,
                                                                const double *B, int ldb, double *C, int ldc)
 {
-    constexpr int NT = WGM * WGN * 64; // 512
+    constexpr int DBM = BT, DBN = BT;
+    constexpr int NT = WGM * WGN * 64;
     constexpr int TI = DBN / 16 / WGM, TJ = DBM / 16 / WGN; // accumulator tiles per wave: rows (N side) x columns (M side)
-    static_assert(NT == 512, "staging below assumes 512 threads");
+    constexpr int TPR = BT / 4;                             // threads per staged row of BT doubles (4 doubles each)
+    static_assert(NT == 4 * BT, "staging: 16 x BT doubles per operand and k-block, 4 per thread");
     __shared__ __attribute__((aligned(16))) double As[2][DBK][DBM + DPAD]; // op(A)(m, k) at [k][m]
     __shared__ __attribute__((aligned(16))) double Bs[2][DBK][DBN + DPAD]; // B(k, n)     at [k][n]
     // tile -> (m block, n block); consecutive workgroups share the B panel (same n block) -- they run close in time
@@ -59,8 +63,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void dgemm_kernel(int transA, int M
     // staging registers: 4 doubles of A and 4 of B per thread and k-block (16 x 128 doubles / 512 threads)
     double a_st[4], b_st[4];
     auto gload = [&](int k0) {
-        if (!transA) { // row kk = tid / 32, columns 4*(tid % 32)..+3 of the tile
-            const int kk = tid >> 5, mm = (tid & 31) * 4;
+        if (!transA) { // row kk = tid / TPR, columns 4*(tid % TPR)..+3 of the tile
+            const int kk = tid / TPR, mm = (tid % TPR) * 4;
             const int k = k0 + kk;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void dgemm_kernel(int transA, int M
     };
     auto lstore = [&](int buf) {
         if (!transA) {
-            const int kk = tid >> 5, mm = (tid & 31) * 4;
+            const int kk = tid / TPR, mm = (tid % TPR) * 4;
 #pragma unroll
             for (int u = 0; u < 4; ++u) As[buf][kk][mm + u] = a_st[u];
         } else {
@@ -273,9 +277,13 @@ int fl_dgemm(int transA, int M, int K, int N, const double *A_dev, int lda, cons
     if (lda < (transA ? K : M) || ldb < K || ldc < M) return FL_ERR_INVALID_ARGUMENT;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FL_ERR_NO_DEVICE;
-    const int tiles = ((M + fl::DBM - 1) / fl::DBM) * ((N + fl::DBN - 1) / fl::DBN);
-    hipLaunchKernelGGL((fl::dgemm_kernel<2, 4>), dim3(tiles), dim3(512), 0, static_cast<hipStream_t>(stream), transA ? 1 : 0,
-                       M, K, N, A_dev, lda, B_dev, ldb, C_dev, ldc);
+    const int tiles128 = ((M + 127) / 128) * ((N + 127) / 128), tiles64 = ((M + 63) / 64) * ((N + 63) / 64);
+    if (tiles128 >= 256) // at least one 128-tile per CU
+        hipLaunchKernelGGL((fl::dgemm_kernel<128, 2, 4>), dim3(tiles128), dim3(512), 0, static_cast<hipStream_t>(stream),
+                           transA ? 1 : 0, M, K, N, A_dev, lda, B_dev, ldb, C_dev, ldc);
+    else
+        hipLaunchKernelGGL((fl::dgemm_kernel<64, 2, 2>), dim3(tiles64), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           transA ? 1 : 0, M, K, N, A_dev, lda, B_dev, ldb, C_dev, ldc);
     return fl::launch_status();
 }
 
@@ -306,7 +314,7 @@ int fl_dsyev_jacobi(char jobz, int n, double *A_dev, int lda, double *w_dev, voi
     hipLaunchKernelGGL(fl::jacobi_init_kernel, dim3(n), dim3(256), 0, st, n, A_dev, V, n);
     int sweeps = 0;
     bool done = (n == 1);
-    double h[2];
+    double h[2], off_prev = -1.0;
     while (!done && sweeps < max_sweeps) {
         for (int step = 0; step < n2 - 1; ++step) {
             hipLaunchKernelGGL(fl::jacobi_cols_kernel, dim3((n + 255) / 256, n2 / 2), dim3(256), 0, st, n, n2, step, A_dev, Bm,
@@ -319,8 +327,12 @@ int fl_dsyev_jacobi(char jobz, int n, double *A_dev, int lda, double *w_dev, voi
         hipLaunchKernelGGL(fl::jacobi_norms_kernel, dim3(n), dim3(256), 0, st, n, A_dev, n, nrm);
         if (hipMemcpyAsync(h, nrm, sizeof h, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
             return FL_ERR_LAUNCH;
-        // off(A)^2 <= eps^2 ||A||_F^2: every eigenvalue is then within eps ||A|| of a diagonal entry
-        done = 2.0 * h[0] <= (2.2e-16 * 2.2e-16) * (2.0 * h[0] + h[1]);
+        // off(A) <= n eps ||A||_F -- the level rounding keeps the off-diagonal part at (every element is rotated ~n times
+        // per sweep) -- or off(A) has stopped shrinking below 1e-12 ||A||_F (quadratic convergence has hit that floor).
+        // Every eigenvalue is then within off(A) of a diagonal entry.
+        const double off2 = 2.0 * h[0], fro2 = 2.0 * h[0] + h[1], tol = (n > 4 ? n : 4) * 2.2e-16;
+        done = off2 <= tol * tol * fro2 || (off_prev >= 0.0 && off2 <= 1e-24 * fro2 && off2 > 0.25 * off_prev);
+        off_prev = off2;
     }
     hipLaunchKernelGGL(fl::jacobi_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, A_dev, n, w_dev);
     if (sweeps_out) *sweeps_out = done ? sweeps : -sweeps;

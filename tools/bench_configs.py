@@ -184,6 +184,40 @@ def main():
                           "final_f_rel_err_max_vs_cpu_rank2_reference_order": float(np.max(
                               np.abs(out["f"][:Bc].cpu().numpy() - ref["f"]) / np.maximum(np.abs(ref["f"]), 1e-300)))}))
 
+    if "dgemm" in args.configs:  # My_dgemm / My_dgemm_T on the f64 matrix cores (fl_dgemm), square problems
+        for n in (1024, 4096, 8192):
+            A = torch.randn(n, n, dtype=torch.float64, device=dev)
+            Bm = torch.randn(n, n, dtype=torch.float64, device=dev)
+            for tA in (False, True):
+                out, ms = timed(lambda: NLO.dgemm(A, Bm, transA=tA), 5)
+                ref = (Bm @ (A.T if tA else A)) if n <= 4096 else None  # column-major C = op(A) B  <=>  row-major B^T-view product
+                err = float((out - ref).abs().max() / (ref.abs().max())) if ref is not None else None
+                flop = 2.0 * n ** 3
+                print(json.dumps({"config": f"dgemm {'T' if tA else 'N'}N n={n} (fl_dgemm, v_mfma_f64_16x16x4_f64)", "ms": ms,
+                                  "TFLOPs": flop / ms / 1e9, "peak_TFLOPs_datasheet": 78.6, "frac": flop / ms / 1e9 / 78.6,
+                                  "max_rel_err_vs_torch_matmul": err}))
+
+    if "dsyev" in args.configs:  # My_dsyev (cyclic Jacobi on the GPU) through the legacy symbol: host arrays in and out
+        import ctypes as C
+        from FortranLibrary.basic import FL
+        dp = C.POINTER(C.c_double)
+        for n in (64, 200, 1024, 2048):
+            G = np.random.default_rng(n).standard_normal((n, n))
+            A0 = np.asfortranarray(0.5 * (G + G.T))
+            for job in (b"N", b"V"):
+                S, w = A0.copy(order="F"), np.zeros(n)
+                t = time.perf_counter()
+                FL.__linearalgebra_MOD_my_dsyev(job, S.ctypes.data_as(dp), w.ctypes.data_as(dp), C.byref(C.c_int(n)), C.c_int(1))
+                dt = time.perf_counter() - t
+                t = time.perf_counter()
+                wr = np.linalg.eigvalsh(A0) if job == b"N" else np.linalg.eigh(A0)[0]
+                dtn = time.perf_counter() - t
+                res = float(np.abs(A0 @ S - S * w[None, :]).max()) if job == b"V" else None
+                print(json.dumps({"config": f"My_dsyev '{job.decode()}' n={n} (cyclic Jacobi, 2 launches per step)",
+                                  "ms_wall_incl_copies": dt * 1e3, "numpy_lapack_ms_on_this_host": dtn * 1e3,
+                                  "eigenvalue_err_max_vs_lapack": float(np.abs(w - wr).max()),
+                                  "residual_max": res, "norm1": float(np.abs(A0).sum(axis=1).max())}))
+
     if "c4gemm" in args.configs:  # the as-written two-matmul update on the f64 matrix cores
         B, n = 16, 4096
         T, E = NLO.reduction_geometry(n)
