@@ -791,6 +791,7 @@ template <int OBJ, int METHOD> struct BigSolver {
     }
 
     // ---------------------------------------------------------------- reverse communication: park / resume
+    // (ownership rules of the parked state: fl_device.hpp, above Solver::save -- rule 3 is the barrier that ends load())
     __device__ __forceinline__ void save(double *sc, double *rho, double fv_c, double pv_c)
     {
         if constexpr (METHOD == FL_SOLVER_LBFGS || METHOD == FL_SOLVER_BFGS) { // rho ring / rho_l, cs_l of pending updates

@@ -1396,7 +1396,30 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
 
     // ---------------------------------------------------------------- reverse communication
     // The machine parked in HBM between two launches of the step kernel (fl_rci.hip):
-    // sc[RCI_SCALARS] doubles, vec[3][NPAD] = p, x0, gold, rho[FL_MAX_MEMORY].
+    // sc[RCI_SCALARS] doubles, vec[4][NPAD] = p, x0, gold, g, rho[FL_MAX_MEMORY].
+    //
+    // OWNERSHIP OF THE PARKED STATE (who may touch what, between which barriers).  Derived from the race of round 1
+    // (n = 5001 through the legacy symbols: fused and reverse-communication L-BFGS differed by 1e-11; the scalar block
+    // of a problem was rewritten by thread 0 while a slower wave was still reading it) -- keep it true when editing
+    // rci_step_kernel, rci_step_big_kernel (fl_big.hpp has the same save / load pair) or line_search_step_kernel:
+    //   1. One workgroup owns one problem's parked state for the whole launch; no other workgroup reads or writes it.
+    //      Launches on the handle's stream are ordered, so a launch sees everything the previous one stored.
+    //   2. VECTOR rows (vec, the history ring, the deferred-update rows, H): element e is loaded and stored only by
+    //      the thread that owns e (Geo::e0 / BigSolver::e_of).  A thread therefore reads back its own stores in
+    //      program order; no barrier is needed, and none may be assumed by code that makes a thread read ANOTHER
+    //      thread's element (Rosenbrock's neighbours, the broadcast arrays of the dense phases, the fold's staging
+    //      area: each of those has its own __syncthreads pair, written next to it).
+    //   3. SCALAR block sc[] and rho[]: read by EVERY thread in load(), written by THREAD 0 ALONE in save() (rho: by
+    //      the first FL_MAX_MEMORY threads after a barrier).  Between the two there must be a workgroup barrier that
+    //      every wave passes AFTER its last read of sc[]: load() ends with that barrier.  Do not rely on the
+    //      reductions' barriers for this -- a step that only takes an objective value (FL_REQ_F pending) performs no
+    //      reduction at all before save().
+    //   4. The early exit of a finished problem (phase == PH_DONE: the kernel returns right after load()) writes
+    //      nothing but request[prob] = 0, by thread 0.
+    //   5. LDS copies of parked values (g_old in g0_park(), rho in L_RHO) follow rule 2 / rule 3 respectively: the
+    //      g_old row is per-thread private; rho_s[] is written before the barrier at the end of load() and by thread 0
+    //      (one new entry) inside direction_lbfgs before its own barrier.
+    // line_search_step_kernel keeps the same discipline with its own barrier after reading sc[] (fl_rci.hip).
     static constexpr int RCI_SCALARS = 48;
     __device__ __forceinline__ void save(double *sc, double *vec, double *rho, double fv_c, double pv_c)
     {
