@@ -315,6 +315,47 @@ def minimize_rci(solver, x, fun, options=None, max_steps=10000000, check_every=8
     return out
 
 
+def minimize_rci_auglag(solver, x, fun, M, lambda0=None, miu0=1.0, options=None, max_steps=10000000, check_every=8, **kw):
+    """AugmentedLagrangian (NO.f90:2005) for a batch with the caller's objective AND equality constraints, by reverse
+    communication: `fun(x)` returns (f[batch], g[batch, n], c[batch, M], cd[batch, M, n]) CUDA tensors for the whole
+    batch (cd[k, j] = grad c_j at x_k).  solver: LBFGS_ | CG (the inner solver).  x is updated in place; returns the
+    usual outputs plus "lambda" [batch, M], "cnorm2", "outer"."""
+    import torch
+    o = options if options is not None else default_options(solver, **kw)
+    B, n, out = _prep(x, None, None)
+    lam = torch.zeros(B, M, dtype=torch.float64, device=x.device) if lambda0 is None else \
+        lambda0.to(torch.float64).contiguous().clone()
+    FL.fl_rci_create_auglag.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double,
+                                        C.POINTER(Options), C.c_void_p]
+    FL.fl_rci_step_auglag.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    FL.fl_rci_results_auglag.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    h = C.c_void_p()
+    _check(FL.fl_rci_create_auglag(C.byref(h), solver, B, n, M, _ptr(lam), float(miu0), C.byref(o), _stream()),
+           "fl_rci_create_auglag")
+    try:
+        req = torch.empty(B, dtype=torch.int32, device=x.device)
+        _check(FL.fl_rci_step_auglag(h, _ptr(x), None, None, None, None, _ptr(req)), "fl_rci_step_auglag")
+        steps = 0
+        while steps < max_steps:
+            if steps % check_every == 0 and not bool((req != 0).any()):
+                break
+            fn, gn, cn, cdn = (t.to(torch.float64).contiguous() for t in fun(x))
+            _check(FL.fl_rci_step_auglag(h, _ptr(x), _ptr(fn), _ptr(gn), _ptr(cn), _ptr(cdn), _ptr(req)),
+                   "fl_rci_step_auglag")
+            steps += 1
+        _check(FL.fl_rci_results(h, _ptr(out["f"]), _ptr(out["gg"]), _ptr(out["iters"]), _ptr(out["status"]),
+                                 _ptr(out["nf"]), _ptr(out["ng"])), "fl_rci_results")
+        out["cnorm2"] = torch.empty(B, dtype=torch.float64, device=x.device)
+        out["outer"] = torch.empty(B, dtype=torch.int32, device=x.device)
+        _check(FL.fl_rci_results_auglag(h, _ptr(out["cnorm2"]), _ptr(out["outer"])), "fl_rci_results_auglag")
+        torch.cuda.synchronize()
+        out["steps"] = steps
+        out["lambda"] = lam
+    finally:
+        FL.fl_rci_destroy(h)
+    return out
+
+
 def dgemm(A, B, transA=False):
     """My_dgemm / My_dgemm_T on device tensors.  Column-major operands given as torch tensors of the TRANSPOSED shape
     (a row of the tensor = a column of the matrix): A [K, M] holds the M x K matrix (transA: A [M, K] holds the K x M

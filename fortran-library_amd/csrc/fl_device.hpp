@@ -23,6 +23,8 @@
 
 #define FL_REQ_NOMOVE 8 // evaluate at the current x (do not form x0 + a p)
 #define FL_REQ_H 16     // reverse communication: the Hessian at the current x is wanted (fdd, NO.f90:37)
+#define FL_REQ_C 32     // reverse communication, augmented Lagrangian: c(x) is wanted (subroutine c, NO.f90:1928)
+#define FL_REQ_CD 64    // ... and the constraint Jacobian cd(x) (subroutine cd: cdx(N,M), NO.f90:1931)
 #define FL_MAX_CONSTRAINTS 16
 
 namespace fl {
@@ -502,11 +504,13 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
         cc = 0.0;
         miu = 0.0;
         if constexpr (AUG) {
-            const int w = n / A.aug_m;
+            if constexpr (OBJ != FL_OBJ_EXTERNAL) { // the built-in constraint family: block spheres
+                const int w = n / A.aug_m;
 #pragma unroll
-            for (int k = 0; k < EPT; ++k) {
-                const int e = G::e0(k >> 1) + (k & 1);
-                blk[k] = (e < n) ? e / w : -1;
+                for (int k = 0; k < EPT; ++k) {
+                    const int e = G::e0(k >> 1) + (k & 1);
+                    blk[k] = (e < n) ? e / w : -1;
+                }
             }
             miu = A.miu0 > 1.0 ? A.miu0 : 1.0; // miu=max(1d0,miu0)
             if ((int)threadIdx.x < A.aug_m) lds[L_LAM + threadIdx.x] = A.lambda[(size_t)prob * A.aug_m + threadIdx.x];
@@ -618,6 +622,46 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
             f = uni(Obj::combine(r[0], r[1]));
             gp = uni(r[2]);
             ggo = uni(r[3]);
+        }
+    }
+
+    // Reverse communication with the CALLER's constraints (AugmentedLagrangian's c, cd callbacks, NO.f90:1928-1934):
+    // L = f - lambda.c + miu/2 c.c (L, NO.f90:2198) and, with the caller's gradient already in g,
+    // grad L = fd + matmul(cdx, miu*cx - lambda) (Ld, NO.f90:2205; cd_user: [m][n], row j = grad c_j), then g.p, g.g.
+    // The sum over the constraints is taken per element in the order j = 0, 1, ... like the oracle's restatement.
+    __device__ __forceinline__ void take_external_aug(double fuser, bool have_f, bool have_g, const double *c_user,
+                                                      const double *cd_user, double &f, double &gp, double &ggo)
+    {
+        const int m = A.aug_m;
+        double *cxs = lds + L_CX;
+        __syncthreads(); // readers of the previous c(x) are done
+        if ((int)threadIdx.x < m) cxs[threadIdx.x] = c_user[threadIdx.x];
+        __syncthreads();
+        if (have_f) {
+            double lc = 0.0, c2 = 0.0;
+            for (int j = 0; j < m; ++j) {
+                lc = lc + lds[L_LAM + j] * cxs[j];
+                c2 = c2 + cxs[j] * cxs[j];
+            }
+            f = uni(fuser - lc + miu / 2.0 * c2);
+        }
+        if (have_g) {
+            double t[EPT];
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) t[k] = 0.0;
+            for (int j = 0; j < m; ++j) {
+                const double v = miu * cxs[j] - lds[L_LAM + j];
+                double row[EPT];
+                load_user<NW, EPT>(cd_user + (size_t)j * n, n, row);
+#pragma unroll
+                for (int k = 0; k < EPT; ++k) t[k] = t[k] + row[k] * v;
+            }
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) g[k] = g[k] + t[k];
+            double q2[2] = {dot_part<EPT>(g, p), dot_part<EPT>(g, g)};
+            R.run(q2);
+            gp = uni(q2[0]);
+            ggo = uni(q2[1]);
         }
     }
 
@@ -1447,6 +1491,17 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
             *iq++ = iters; *iq++ = nf; *iq++ = ng; *iq++ = status; *iq++ = phase; *iq++ = pending;
             *iq++ = recent; *iq++ = cnt; *iq++ = ls.st; *iq++ = ls.zret; *iq++ = ls.fused;
             *iq++ = main_it; *iq++ = h_valid; *iq++ = hess_stage;
+            if constexpr (AUG) { // outer loop of the augmented Lagrangian (the multipliers themselves: A.lambda, below)
+                sc[40] = miu;
+                sc[41] = cc;
+                int *aq = reinterpret_cast<int *>(sc + 42);
+                aq[0] = outer_it;
+                aq[1] = inner_iters_total;
+            }
+        }
+        if constexpr (AUG) { // lambda lives in LDS during a launch and in the caller's array between launches
+            __syncthreads();
+            if ((int)threadIdx.x < A.aug_m) A.lambda[(size_t)prob * A.aug_m + threadIdx.x] = lds[L_LAM + threadIdx.x];
         }
     }
     __device__ __forceinline__ void load(const double *sc, const double *vec, const double *rho, double &fv_c,
@@ -1475,6 +1530,13 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
         iters = *iq++; nf = *iq++; ng = *iq++; status = *iq++; phase = *iq++; pending = *iq++;
         recent = *iq++; cnt = *iq++; ls.st = *iq++; ls.zret = *iq++; ls.fused = *iq++;
         main_it = *iq++; h_valid = *iq++; hess_stage = *iq++;
+        if constexpr (AUG) {
+            miu = sc[40];
+            cc = sc[41];
+            const int *aq = reinterpret_cast<const int *>(sc + 42);
+            outer_it = aq[0];
+            inner_iters_total = aq[1];
+        }
         if constexpr (LEAN) { // the parked scalars arrive as one copy per lane: pin them to scalar registers
             fnew = uni(fnew); gg = uni(gg); pp = uni(pp); phid = uni(phid); phidold = uni(phidold); a = uni(a);
             yy_recent = uni(yy_recent); rho_recent = uni(rho_recent);

@@ -27,12 +27,13 @@
 
 namespace fl {
 
-template <int NW, int EPT, int METHOD>
+template <int NW, int EPT, int METHOD, int AUG = 0>
 __global__ __launch_bounds__(NW * 64) void rci_step_kernel(SolveArgs A, int first, double *sc_all, double *vec_all,
                                                            double *rho_all, const double *f_dev,
-                                                           const double *g_dev, int32_t *request)
+                                                           const double *g_dev, const double *c_dev,
+                                                           const double *cd_dev, int32_t *request)
 {
-    using S = Solver<NW, EPT, FL_OBJ_EXTERNAL, METHOD, 0>;
+    using S = Solver<NW, EPT, FL_OBJ_EXTERNAL, METHOD, AUG>;
     __shared__ __attribute__((aligned(16))) double lds[S::LDS_TOTAL];
     S s(A, lds);
     const int prob = blockIdx.x, n = A.n;
@@ -51,13 +52,22 @@ __global__ __launch_bounds__(NW * 64) void rci_step_kernel(SolveArgs A, int firs
             return;
         }
         double ggv = s.gg;
-        if ((s.pending & FL_REQ_F) && f_dev) fv = f_dev[prob];
-        if ((s.pending & FL_REQ_G) && g_dev) {
-            load_user<NW, EPT>(g_dev + (size_t)prob * n, n, s.g);
-            double q[2] = {dot_part<EPT>(s.g, s.p), dot_part<EPT>(s.g, s.g)};
-            s.R.run(q);
-            pv = q[0];
-            ggv = q[1];
+        const bool have_f = (s.pending & FL_REQ_F) && f_dev, have_g = (s.pending & FL_REQ_G) && g_dev;
+        if constexpr (AUG) {
+            // the caller's f, grad f, c, cd -> the augmented Lagrangian and its gradient (c comes with every request,
+            // cd with every gradient request: the request bits FL_REQ_C / FL_REQ_CD say so)
+            if (have_g) load_user<NW, EPT>(g_dev + (size_t)prob * n, n, s.g);
+            s.take_external_aug(have_f ? f_dev[prob] : 0.0, have_f, have_g, c_dev + (size_t)prob * A.aug_m,
+                                cd_dev + (size_t)prob * A.aug_m * n, fv, pv, ggv);
+        } else {
+            if (have_f) fv = f_dev[prob];
+            if (have_g) {
+                load_user<NW, EPT>(g_dev + (size_t)prob * n, n, s.g);
+                double q[2] = {dot_part<EPT>(s.g, s.p), dot_part<EPT>(s.g, s.g)};
+                s.R.run(q);
+                pv = q[0];
+                ggv = q[1];
+            }
         }
         rq = s.advance(fv, pv, ggv);
     }
@@ -68,7 +78,11 @@ __global__ __launch_bounds__(NW * 64) void rci_step_kernel(SolveArgs A, int firs
         store_user<NW, EPT>(A.x + (size_t)prob * n, n, s.x);
     }
     s.save(sc, vec, rho, fv, pv);
-    if (threadIdx.x == 0) request[prob] = rq;
+    if (threadIdx.x == 0) {
+        int out = rq;
+        if (AUG && rq != 0) out |= FL_REQ_C | ((rq & FL_REQ_G) ? FL_REQ_CD : 0);
+        request[prob] = out;
+    }
 }
 
 // n > 4096 (fl_big.hpp): the same step with the machine's vectors in HBM, one workgroup of 1024 threads per problem
@@ -172,18 +186,30 @@ __global__ __launch_bounds__(NW * 64) void line_search_step_kernel(int n, int ns
 
 struct Rci {
     int solver, batch, n, nw, ept, first;
+    int aug; // augmented Lagrangian around the inner solver: c, cd come with the evaluations
+    int32_t *outer;
+    double *cnorm2;
     SolveArgs A;
     double *sc, *vec, *rho, *ws, *f_out, *gg_out;
     int32_t *iters, *status, *nf, *ng;
     hipStream_t stream;
 };
 
-template <int NW, int EPT> static void launch_rci(Rci *h, const double *f, const double *g, int32_t *req)
+template <int NW, int EPT>
+static void launch_rci(Rci *h, const double *f, const double *g, const double *c, const double *cd, int32_t *req)
 {
     dim3 grid(h->batch), block(NW * 64);
 #define FL_RCI(M)                                                                                                 \
-    hipLaunchKernelGGL((rci_step_kernel<NW, EPT, M>), grid, block, 0, h->stream, h->A, h->first, h->sc, h->vec,   \
-                       h->rho, f, g, req)
+    hipLaunchKernelGGL((rci_step_kernel<NW, EPT, M, 0>), grid, block, 0, h->stream, h->A, h->first, h->sc, h->vec, \
+                       h->rho, f, g, c, cd, req)
+#define FL_RCI_AUG(M)                                                                                             \
+    hipLaunchKernelGGL((rci_step_kernel<NW, EPT, M, 1>), grid, block, 0, h->stream, h->A, h->first, h->sc, h->vec, \
+                       h->rho, f, g, c, cd, req)
+    if (h->aug) { // AugmentedLagrangian around L-BFGS (NO.f90:2150-2167) or ConjugateGradient (2168-2185)
+        if (h->solver == FL_SOLVER_CG) FL_RCI_AUG(FL_SOLVER_CG);
+        else FL_RCI_AUG(FL_SOLVER_LBFGS);
+        return;
+    }
     switch (h->solver) {
     case FL_SOLVER_SD: FL_RCI(FL_SOLVER_SD); break;
     case FL_SOLVER_CG: FL_RCI(FL_SOLVER_CG); break;
@@ -192,6 +218,7 @@ template <int NW, int EPT> static void launch_rci(Rci *h, const double *f, const
     default: FL_RCI(FL_SOLVER_LBFGS); break;
     }
 #undef FL_RCI
+#undef FL_RCI_AUG
 }
 
 static void launch_rci_big(Rci *h, const double *f, const double *g, int32_t *req)
@@ -221,7 +248,7 @@ int fl_rci_destroy(fl_rci *h)
 {
     if (!h) return FL_OK;
     void *bufs[] = {h->r.sc, h->r.vec, h->r.rho, h->r.ws, h->r.f_out, h->r.gg_out, h->r.iters, h->r.status,
-                    h->r.nf, h->r.ng};
+                    h->r.nf, h->r.ng, h->r.outer, h->r.cnorm2};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     delete h;
@@ -307,23 +334,78 @@ int fl_rci_create(fl_rci **out, int solver, int batch, int n, const fl_options *
     return FL_OK;
 }
 
-int fl_rci_step(fl_rci *h, double *x_dev, const double *f_dev, const double *g_dev, int32_t *request_dev)
+static int rci_step_any(fl_rci *h, double *x_dev, const double *f_dev, const double *g_dev, const double *c_dev,
+                        const double *cd_dev, int32_t *request_dev)
 {
     if (!h || !x_dev || !request_dev) return FL_ERR_INVALID_ARGUMENT;
+    if (h->r.aug && !h->r.first && (!c_dev || !cd_dev)) return FL_ERR_INVALID_ARGUMENT;
     // f_dev / g_dev may be NULL on a step where no problem asked for them (the first step; a step that only delivers
     // Hessians, FL_REQ_H): the kernels read an array only for the problems whose request bit names it
     fl::Rci *r = &h->r;
     r->A.x = x_dev;
     const int nw = r->nw, ept = r->ept;
     if (nw == 16) fl::launch_rci_big(r, f_dev, g_dev, request_dev);
-    else if (nw == 1 && ept == 2) fl::launch_rci<1, 2>(r, f_dev, g_dev, request_dev);
-    else if (nw == 1 && ept == 4) fl::launch_rci<1, 4>(r, f_dev, g_dev, request_dev);
-    else if (nw == 2 && ept == 4) fl::launch_rci<2, 4>(r, f_dev, g_dev, request_dev);
-    else if (nw == 2 && ept == 8) fl::launch_rci<2, 8>(r, f_dev, g_dev, request_dev);
-    else if (nw == 4 && ept == 8) fl::launch_rci<4, 8>(r, f_dev, g_dev, request_dev);
-    else fl::launch_rci<8, 8>(r, f_dev, g_dev, request_dev);
+    else if (nw == 1 && ept == 2) fl::launch_rci<1, 2>(r, f_dev, g_dev, c_dev, cd_dev, request_dev);
+    else if (nw == 1 && ept == 4) fl::launch_rci<1, 4>(r, f_dev, g_dev, c_dev, cd_dev, request_dev);
+    else if (nw == 2 && ept == 4) fl::launch_rci<2, 4>(r, f_dev, g_dev, c_dev, cd_dev, request_dev);
+    else if (nw == 2 && ept == 8) fl::launch_rci<2, 8>(r, f_dev, g_dev, c_dev, cd_dev, request_dev);
+    else if (nw == 4 && ept == 8) fl::launch_rci<4, 8>(r, f_dev, g_dev, c_dev, cd_dev, request_dev);
+    else fl::launch_rci<8, 8>(r, f_dev, g_dev, c_dev, cd_dev, request_dev);
     r->first = 0;
     return fl::launch_status();
+}
+
+int fl_rci_step(fl_rci *h, double *x_dev, const double *f_dev, const double *g_dev, int32_t *request_dev)
+{
+    if (h && h->r.aug) return FL_ERR_INVALID_ARGUMENT; // an augmented-Lagrangian handle steps with fl_rci_step_auglag
+    return rci_step_any(h, x_dev, f_dev, g_dev, nullptr, nullptr, request_dev);
+}
+
+// AugmentedLagrangian (NO.f90:2005-2241) for a batch with the CALLER's objective and constraints: create a handle
+// around the inner solver (FL_SOLVER_LBFGS | FL_SOLVER_CG), then step it like fl_rci_step with, in addition,
+// c_dev [batch][m] = c(x) and cd_dev [batch][m][n] = the constraint Jacobian (row j = grad c_j; Fortran cdx(N,M)).
+int fl_rci_create_auglag(fl_rci **out, int solver, int batch, int n, int m, double *lambda_dev, double miu0,
+                         const fl_options *opt, void *stream)
+{
+    if (solver != FL_SOLVER_LBFGS && solver != FL_SOLVER_CG) return FL_ERR_INVALID_ARGUMENT;
+    if (m < 1 || m > FL_MAX_CONSTRAINTS || !lambda_dev) return FL_ERR_INVALID_ARGUMENT;
+    if (n > 4096) return FL_ERR_UNSUPPORTED_SIZE; // like fl_augmented_lagrangian_batched: the register path only
+    const int rc = fl_rci_create(out, solver, batch, n, opt, stream);
+    if (rc != FL_OK) return rc;
+    fl::Rci &r = (*out)->r;
+    const size_t B = (size_t)batch;
+    if (hipMalloc((void **)&r.outer, B * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc((void **)&r.cnorm2, B * sizeof(double)) != hipSuccess) {
+        fl_rci_destroy(*out);
+        *out = nullptr;
+        return FL_ERR_WORKSPACE;
+    }
+    r.aug = 1;
+    r.A.aug_m = m;
+    r.A.miu0 = miu0;
+    r.A.lambda = lambda_dev; // in: lambda0, out: the multipliers (kept up to date from step to step)
+    r.A.outer = r.outer;
+    r.A.cnorm2 = r.cnorm2;
+    return FL_OK;
+}
+
+int fl_rci_step_auglag(fl_rci *h, double *x_dev, const double *f_dev, const double *g_dev, const double *c_dev,
+                       const double *cd_dev, int32_t *request_dev)
+{
+    if (!h || !h->r.aug) return FL_ERR_INVALID_ARGUMENT;
+    return rci_step_any(h, x_dev, f_dev, g_dev, c_dev, cd_dev, request_dev);
+}
+
+// after all requests are 0: c.c at exit and the number of outer iterations per problem (each may be NULL); the other
+// outputs through fl_rci_results (f = the augmented Lagrangian at exit, iters = inner iterations of all outer rounds)
+int fl_rci_results_auglag(fl_rci *h, double *cnorm2_dev, int32_t *outer_dev)
+{
+    if (!h || !h->r.aug) return FL_ERR_INVALID_ARGUMENT;
+    const size_t B = (size_t)h->r.batch;
+    bool ok = true;
+    if (cnorm2_dev) ok &= hipMemcpyAsync(cnorm2_dev, h->r.cnorm2, B * 8, hipMemcpyDeviceToDevice, h->r.stream) == hipSuccess;
+    if (outer_dev) ok &= hipMemcpyAsync(outer_dev, h->r.outer, B * 4, hipMemcpyDeviceToDevice, h->r.stream) == hipSuccess;
+    return ok ? FL_OK : FL_ERR_LAUNCH;
 }
 
 int fl_rci_hessian_buffer(fl_rci *h, double **hessian_dev, int *ld)

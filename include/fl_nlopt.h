@@ -248,6 +248,28 @@ int fl_rci_results(fl_rci *handle, double *f_dev, double *gg_dev, int32_t *iters
                    int32_t *nf_dev, int32_t *ng_dev);
 int fl_rci_destroy(fl_rci *handle);
 
+/* ---- AugmentedLagrangian (NO.f90:2005-2241) for a batch with the CALLER's objective AND constraints -------------
+ * The reference's callbacks c(cx,x,M,N) and cd(cdx(N,M),x,M,N) (NO.f90:1928-1934) join the ask / tell loop: the handle
+ * wraps the inner solver (FL_SOLVER_LBFGS, NO.f90:2150-2167, or FL_SOLVER_CG, 2168-2185; always with f_fd present like
+ * the reference, 2153) in the outer loop lambda <- lambda - miu c, miu <- miu * Increment (2155-2157), per problem and
+ * inside the step kernel.  Requests carry two more bits: FL_RCI_REQ_C (32) -- with EVERY request: c_dev[batch][m] =
+ * c(x) at the requested point -- and FL_RCI_REQ_CD (64) -- with every gradient request: cd_dev[batch][m][n], row j =
+ * grad c_j(x) (the Fortran array cdx(N,M) as it lies in memory).  L = f - lambda.c + miu/2 c.c and
+ * grad L = grad f + cd^T (miu c - lambda) (NO.f90:2198, 2205) are formed in the kernel; m <= 16, n <= 4096.
+ * lambda_dev [batch][m]: lambda0 on entry, the multipliers afterwards (updated in place from step to step; must stay
+ * valid while the handle lives).  opt->precision is the inner gradient tolerance AND the outer ||c|| tolerance,
+ * opt->max_iteration bounds both loops, opt->increment is the line-search growth factor AND the miu growth factor
+ * (as in the reference).  fl_rci_results: f = the augmented Lagrangian at exit, iters = inner iterations of all outer
+ * rounds, status = FL_STATUS_CONVERGED (||c|| < Precision) | FL_STATUS_MAXIT; fl_rci_results_auglag: c.c at exit and
+ * the number of outer iterations. */
+#define FL_RCI_REQ_C 32
+#define FL_RCI_REQ_CD 64
+int fl_rci_create_auglag(fl_rci **handle, int solver, int batch, int n, int m, double *lambda_dev, double miu0,
+                         const fl_options *opt, void *stream);
+int fl_rci_step_auglag(fl_rci *handle, double *x_dev, const double *f_dev, const double *g_dev, const double *c_dev,
+                       const double *cd_dev, int32_t *request_dev);
+int fl_rci_results_auglag(fl_rci *handle, double *cnorm2_dev, int32_t *outer_dev);
+
 /* The L-BFGS two-loop recursion alone (Before(), NO.f90:586-608) for a batch:
  * p = -H_k g from a full ring of `memory` pairs.  hist_dev is the solver's
  * history layout [batch][2*memory][npad] (npad = threads*ept; pair i: s at

@@ -139,6 +139,8 @@ enum { FLO_SD = 0, FLO_CG = 1, FLO_LBFGS = 2, FLO_BFGS = 3 };
 int flo_solve_batch(int solver, int kind, int B, int n, double *x, const double *d, const double *b,
                     const flo_opts *o, int use_ffd, int bfgs_form, int sum_mode, int threads, int ept,
                     int nthreads, double *fout, int *iters, int *status, int *nf, int *ng, double *gg);
+int flo_prob_eval_batch(int kind, int B, int n, int m, const double *x, const double *d, const double *b, int sum_mode,
+                        int threads, int ept, int nthreads, double *f, double *g, double *c, double *cd);
 int flo_auglag_batch(int solver, int kind, int B, int n, int m, double *x, const double *d, const double *b,
                      double *lambda, double miu0, const flo_opts *o, int use_ffd, int sum_mode, int threads,
                      int ept, int nthreads, double *fout, int *iters, int *outer, int *nf, int *ng,

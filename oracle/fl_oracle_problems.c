@@ -227,3 +227,30 @@ int flo_auglag_batch(int solver, int kind, int B, int n, int m, double *x, const
     }
     return used;
 }
+
+/* f, grad f, c, cd of the built-in problems for a whole batch at the given points: what a caller of the
+ * reverse-communication API computes between two steps (tests: the "user" side of fl_rci_step_auglag).
+ * g [B][n], c [B][m], cd [B][m][n] (row j = grad c_j); any output may be NULL. */
+int flo_prob_eval_batch(int kind, int B, int n, int m, const double *x, const double *d, const double *b, int sum_mode,
+                        int threads, int ept, int nthreads, double *f, double *g, double *c, double *cd)
+{
+    int used = 1;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+    used = omp_get_max_threads();
+#pragma omp parallel for schedule(static)
+#endif
+    for (int k = 0; k < B; ++k) {
+        flo_problem P;
+        set_modes(sum_mode, threads, ept);
+        P.kind = kind;
+        P.d = d ? d + (size_t)k * n : NULL;
+        P.b = b ? b + (size_t)k * n : NULL;
+        const double *xk = x + (size_t)k * n;
+        if (f) flo_prob_f(f + k, xk, n, &P);
+        if (g) flo_prob_fd(g + (size_t)k * n, xk, n, &P);
+        if (c) flo_prob_c(c + (size_t)k * m, xk, m, n, &P);
+        if (cd) flo_prob_cd(cd + (size_t)k * m * n, xk, m, n, &P);
+    }
+    return used;
+}

@@ -518,3 +518,56 @@ def test_augmented_lagrangian_config5_vs_reference_order():
     assert abs(fx - (-23.331108193268726)) <= 1e-10 * 23.33
     o = O.auglag_batch(O.LBFGS, O.DIAGQUAD, x0, m, d=d, b=b, opts=O.defaults(precision=1e-10))
     assert np.linalg.norm(g["x"] - o["x"]) <= 1e-8 * np.linalg.norm(o["x"])
+
+
+@pytest.mark.parametrize("solver_name,solver,kind,n,m,kw", [
+    ("LBFGS", O.LBFGS, O.QUARTIC, 10, 1, {"Precision": 1e-8}),      # test/test.f90:452-478 / test.cpp:112-125 as a batch
+    ("LBFGS", O.LBFGS, O.DIAGQUAD, 48, 3, {"Precision": 1e-7}),
+    ("ConjugateGradient", O.CG, O.DIAGQUAD, 48, 3, {"Precision": 1e-6, "MaxIteration": 100}),
+    ("LBFGS", O.LBFGS, O.ROSENBROCK, 96, 3, {"Precision": 1e-7, "Memory": 5}),
+])
+def test_augmented_lagrangian_batch_with_the_callers_constraints_by_reverse_communication(solver_name, solver, kind, n, m, kw):
+    """AugmentedLagrangian for a batch of 256 with f, grad f, c AND cd coming from the caller (fl_rci_*_auglag: the
+    reference's c / cd callbacks, NO.f90:1928-1934, as request bits).  The "caller" here is the oracle's own problem
+    code on the host, so every number must equal flo_auglag_batch (and with it the fused kernel) bit for bit:
+    minimisers, multipliers, c.c, outer / inner iteration and evaluation counts."""
+    import ctypes as C
+    NLO = _nlo()
+    dev = torch.device("cuda:0")
+    B = 256
+    rng = np.random.default_rng(7 * n + m)
+    i = np.arange(1, n + 1).astype(float)
+    x0 = 0.1 + 0.05 * np.cos(i)[None, :] + 0.01 * rng.standard_normal((B, n))
+    if kind == O.QUARTIC:
+        x0 = rng.random((B, n))
+    d = b = None
+    if kind == O.DIAGQUAD:
+        d, b = _quads(B, n, 2.0, 10.0, 5)
+    T, E = NLO.reduction_geometry(n)
+    lib = O.lib()
+    dp = C.POINTER(C.c_double)
+    lib.flo_prob_eval_batch.argtypes = [C.c_int] * 4 + [dp, dp, dp] + [C.c_int] * 4 + [dp] * 4
+    P = lambda a: a.ctypes.data_as(dp) if a is not None else None
+    f_h, g_h, c_h, cd_h = np.zeros(B), np.zeros((B, n)), np.zeros((B, m)), np.zeros((B, m, n))
+
+    def fun(xdev):  # the caller's side of the protocol: evaluate everything at the requested points
+        xh = np.ascontiguousarray(xdev.cpu().numpy())
+        lib.flo_prob_eval_batch(kind, B, n, m, P(xh), P(d), P(b), O.TREE, T, E, 0, P(f_h), P(g_h), P(c_h), P(cd_h))
+        return (torch.tensor(f_h, device=dev), torch.tensor(g_h, device=dev), torch.tensor(c_h, device=dev),
+                torch.tensor(cd_h, device=dev))
+
+    x = torch.tensor(x0, device=dev)
+    out = NLO.minimize_rci_auglag(NLO.LBFGS_ if solver == O.LBFGS else NLO.CG, x, fun, m, check_every=1, **kw)
+    oo = _oracle_opts(solver, kw)
+    o = O.auglag_batch(solver, kind, x0, m, d=d, b=b, opts=oo, sum_mode=O.TREE, threads=T, ept=E)
+    g = {k: v.cpu().numpy() for k, v in out.items() if hasattr(v, "cpu")}
+    assert np.array_equal(g["outer"], o["outer"])
+    assert np.array_equal(g["iters"], o["iters"])
+    assert np.array_equal(g["nf"], o["nf"]) and np.array_equal(g["ng"], o["ng"])
+    assert np.array_equal(x.cpu().numpy().view(np.uint64), o["x"].view(np.uint64))
+    assert np.array_equal(g["lambda"].view(np.uint64), o["lam"].view(np.uint64))
+    assert np.array_equal(g["cnorm2"].view(np.uint64), o["cnorm2"].view(np.uint64))
+    assert np.all(g["cnorm2"] < oo.precision ** 2) or kw.get("MaxIteration")
+    # ... and the fused kernel with its compiled-in block spheres gives the same (three ways to the same bits)
+    fused = _gpu_auglag(solver_name, kind, x0, m, d, b, **kw)
+    assert np.array_equal(fused["x"].view(np.uint64), o["x"].view(np.uint64))
