@@ -520,21 +520,20 @@ def test_augmented_lagrangian_config5_vs_reference_order():
     assert np.linalg.norm(g["x"] - o["x"]) <= 1e-8 * np.linalg.norm(o["x"])
 
 
-@pytest.mark.parametrize("solver_name,solver,kind,n,m,kw", [
-    ("LBFGS", O.LBFGS, O.QUARTIC, 10, 1, {"Precision": 1e-8}),      # test/test.f90:452-478 / test.cpp:112-125 as a batch
-    ("LBFGS", O.LBFGS, O.DIAGQUAD, 48, 3, {"Precision": 1e-7}),
-    ("ConjugateGradient", O.CG, O.DIAGQUAD, 48, 3, {"Precision": 1e-6, "MaxIteration": 100}),
-    ("LBFGS", O.LBFGS, O.ROSENBROCK, 96, 3, {"Precision": 1e-7, "Memory": 5}),
+@pytest.mark.parametrize("solver_name,solver,kind,n,m,B,kw", [
+    ("LBFGS", O.LBFGS, O.QUARTIC, 10, 1, 256, {"Precision": 1e-8}),  # test/test.f90:452-478 / test.cpp:112-125 as a batch
+    ("LBFGS", O.LBFGS, O.DIAGQUAD, 48, 3, 64, {"Precision": 1e-7}),
+    ("ConjugateGradient", O.CG, O.DIAGQUAD, 48, 3, 32, {"Precision": 1e-6, "MaxIteration": 100}),
+    ("LBFGS", O.LBFGS, O.ROSENBROCK, 96, 3, 16, {"Precision": 1e-7, "Memory": 5}),
 ])
-def test_augmented_lagrangian_batch_with_the_callers_constraints_by_reverse_communication(solver_name, solver, kind, n, m, kw):
-    """AugmentedLagrangian for a batch of 256 with f, grad f, c AND cd coming from the caller (fl_rci_*_auglag: the
+def test_augmented_lagrangian_batch_with_the_callers_constraints_by_reverse_communication(solver_name, solver, kind, n, m, B, kw):
+    """AugmentedLagrangian for a batch (up to 256) with f, grad f, c AND cd coming from the caller (fl_rci_*_auglag: the
     reference's c / cd callbacks, NO.f90:1928-1934, as request bits).  The "caller" here is the oracle's own problem
     code on the host, so every number must equal flo_auglag_batch (and with it the fused kernel) bit for bit:
     minimisers, multipliers, c.c, outer / inner iteration and evaluation counts."""
     import ctypes as C
     NLO = _nlo()
     dev = torch.device("cuda:0")
-    B = 256
     rng = np.random.default_rng(7 * n + m)
     i = np.arange(1, n + 1).astype(float)
     x0 = 0.1 + 0.05 * np.cos(i)[None, :] + 0.01 * rng.standard_normal((B, n))
