@@ -31,14 +31,27 @@ namespace fl {
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 constexpr int DBK = 16, DPAD = 16; // DPAD: rows of the LDS image 32 banks apart
 
+struct GemmArgs {
+    int transA, transB, M, K, N, lda, ldb, ldc, lower;
+    double alpha, beta;
+    const double *A, *B;
+    double *C;
+    size_t strideA, strideB, strideC;
+};
+
 // X is "index-contiguous" (element (idx, k) at idx + k*ld): A for 'N'.  Thread t stages 8 doubles of row kk.
 // X is "k-contiguous"     (element (idx, k) at k + idx*ld): A for 'T', and B.  Thread t stages k = 8*(t&1).. of idx t>>1.
 // BT x BT tile per workgroup of WGM x WGN waves = BT*4 threads: 128 (2 x 4 waves, 8 accumulator tiles per wave) for
 // large problems, 64 (2 x 2 waves, 4 tiles) while 128-tiles would leave CUs idle (n = 1024: 64 tiles for 256 CUs).
 template <int BT, int WGM, int WGN>
-__global__ __launch_bounds__(WGM * WGN * 64) void dgemm_kernel(int transA, int M, int K, int N, const double *A, int lda,
-                                                               const double *B, int ldb, double *C, int ldc)
+__global__ __launch_bounds__(WGM * WGN * 64) void dgemm_kernel(GemmArgs g)
 {
+    // C = alpha op(A) op(B) + beta C for matrix blockIdx.y of a strided batch.  transB: B is given N x K (element
+    // (k, n) at n + k*ldb) -- the layout of L21 in "A22 -= L21 L21^T".  lower: only the tiles that touch the lower
+    // triangle (m >= n) are computed (symmetric rank-k updates of a matrix whose upper triangle is not referenced).
+    const int transA = g.transA, transB = g.transB, M = g.M, K = g.K, N = g.N, lda = g.lda, ldb = g.ldb, ldc = g.ldc;
+    const double *A = g.A + (size_t)blockIdx.y * g.strideA, *B = g.B + (size_t)blockIdx.y * g.strideB;
+    double *C = g.C + (size_t)blockIdx.y * g.strideC;
     constexpr int DBM = BT, DBN = BT;
     constexpr int NT = WGM * WGN * 64;
     constexpr int TI = DBN / 16 / WGM, TJ = DBM / 16 / WGN; // accumulator tiles per wave: rows (N side) x columns (M side)
@@ -50,6 +63,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void dgemm_kernel(int transA, int M
     const int tiles_m = (M + DBM - 1) / DBM;
     const int tm = blockIdx.x % tiles_m, tn = blockIdx.x / tiles_m;
     const int m0 = tm * DBM, n0 = tn * DBN;
+    if (g.lower && m0 + DBM <= n0) return; // the whole tile lies above the diagonal
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave / WGN, wj = wave % WGN; // wave's block of the tile: rows (n) wi, columns (m) wj
     const int lr = lane & 15, lq = lane >> 4;
@@ -80,7 +94,15 @@ __global__ __launch_bounds__(WGM * WGN * 64) void dgemm_kernel(int transA, int M
                 a_st[u] = (k < K && m < M) ? A[(size_t)m * lda + k] : 0.0;
             }
         }
-        {
+        if (transB) { // row kk = tid / TPR, columns 4*(tid % TPR)..+3: (k, n) at n + k*ldb
+            const int kk = tid / TPR, nn = (tid % TPR) * 4;
+            const int k = k0 + kk;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int n = n0 + nn + u;
+                b_st[u] = (k < K && n < N) ? B[(size_t)k * ldb + n] : 0.0;
+            }
+        } else {
             const int nn = tid >> 2, kk = (tid & 3) * 4;
             const int n = n0 + nn;
 #pragma unroll
@@ -100,9 +122,15 @@ __global__ __launch_bounds__(WGM * WGN * 64) void dgemm_kernel(int transA, int M
 #pragma unroll
             for (int u = 0; u < 4; ++u) As[buf][kk + u][mm] = a_st[u];
         }
-        const int nn = tid >> 2, kk = (tid & 3) * 4;
+        if (transB) {
+            const int kk = tid / TPR, nn = (tid % TPR) * 4;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) Bs[buf][kk + u][nn] = b_st[u];
+            for (int u = 0; u < 4; ++u) Bs[buf][kk][nn + u] = b_st[u];
+        } else {
+            const int nn = tid >> 2, kk = (tid & 3) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) Bs[buf][kk + u][nn] = b_st[u];
+        }
     };
     gload(0);
     lstore(0);
@@ -138,7 +166,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void dgemm_kernel(int transA, int M
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) {
                     const int m = m0 + 16 * TJ * wj + 16 * j + lr;
-                    if (m < M) C[(size_t)n * ldc + m] = acc[i][j][r];
+                    if (m < M) {
+                        double *cp = C + (size_t)n * ldc + m;
+                        *cp = (g.beta == 0.0) ? g.alpha * acc[i][j][r] : g.alpha * acc[i][j][r] + g.beta * *cp;
+                    }
                 }
             }
         }
@@ -270,21 +301,38 @@ __global__ void jacobi_diag_kernel(int n, const double *A, int ld, double *w)
 
 extern "C" {
 
+// launcher shared by fl_dgemm and the blocked Cholesky routines (fl_chol_blocked.hip)
+int fl_dgemm_strided(int transA, int transB, int M, int K, int N, double alpha, const double *A_dev, int lda, size_t strideA,
+                     const double *B_dev, int ldb, size_t strideB, double beta, double *C_dev, int ldc, size_t strideC,
+                     int batch, int lower_only, void *stream)
+{
+    if (!A_dev || !B_dev || !C_dev || M <= 0 || N <= 0 || K < 0 || batch <= 0) return FL_ERR_INVALID_ARGUMENT;
+    if (lda < (transA ? K : M) || ldb < (transB ? N : K) || ldc < M) return FL_ERR_INVALID_ARGUMENT;
+    fl::GemmArgs g;
+    g.transA = transA ? 1 : 0;
+    g.transB = transB ? 1 : 0;
+    g.M = M; g.K = K; g.N = N; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.lower = lower_only ? 1 : 0;
+    g.alpha = alpha; g.beta = beta;
+    g.A = A_dev; g.B = B_dev; g.C = C_dev;
+    g.strideA = strideA; g.strideB = strideB; g.strideC = strideC;
+    const int tiles128 = ((M + 127) / 128) * ((N + 127) / 128), tiles64 = ((M + 63) / 64) * ((N + 63) / 64);
+    if ((long long)tiles128 * batch >= 256) // at least one 128-tile per CU
+        hipLaunchKernelGGL((fl::dgemm_kernel<128, 2, 4>), dim3(tiles128, batch), dim3(512), 0,
+                           static_cast<hipStream_t>(stream), g);
+    else
+        hipLaunchKernelGGL((fl::dgemm_kernel<64, 2, 2>), dim3(tiles64, batch), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           g);
+    return fl::launch_status();
+}
+
 int fl_dgemm(int transA, int M, int K, int N, const double *A_dev, int lda, const double *B_dev, int ldb, double *C_dev,
              int ldc, void *stream)
 {
-    if (!A_dev || !B_dev || !C_dev || M <= 0 || N <= 0 || K <= 0) return FL_ERR_INVALID_ARGUMENT;
-    if (lda < (transA ? K : M) || ldb < K || ldc < M) return FL_ERR_INVALID_ARGUMENT;
+    if (K <= 0) return FL_ERR_INVALID_ARGUMENT;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FL_ERR_NO_DEVICE;
-    const int tiles128 = ((M + 127) / 128) * ((N + 127) / 128), tiles64 = ((M + 63) / 64) * ((N + 63) / 64);
-    if (tiles128 >= 256) // at least one 128-tile per CU
-        hipLaunchKernelGGL((fl::dgemm_kernel<128, 2, 4>), dim3(tiles128), dim3(512), 0, static_cast<hipStream_t>(stream),
-                           transA ? 1 : 0, M, K, N, A_dev, lda, B_dev, ldb, C_dev, ldc);
-    else
-        hipLaunchKernelGGL((fl::dgemm_kernel<64, 2, 2>), dim3(tiles64), dim3(256), 0, static_cast<hipStream_t>(stream),
-                           transA ? 1 : 0, M, K, N, A_dev, lda, B_dev, ldb, C_dev, ldc);
-    return fl::launch_status();
+    return fl_dgemm_strided(transA, 0, M, K, N, 1.0, A_dev, lda, 0, B_dev, ldb, 0, 0.0, C_dev, ldc, 0, 1, 0, stream);
 }
 
 size_t fl_dsyev_workspace_bytes(int n)

@@ -5,6 +5,7 @@
 // Hessian refresh of BFGS use inside the fused solver).
 #include "fl_device.hpp"
 #include "fl_host.hpp"
+#include <stdlib.h>
 
 namespace fl {
 
@@ -178,16 +179,57 @@ extern "C" {
         else return FL_ERR_UNSUPPORTED_SIZE; /* a geometry none of the dense kernels is built for */                 \
     } while (0)
 
+// Beyond this order the blocked multi-workgroup Cholesky (fl_chol_blocked.hip: O(n^3) on the f64 matrix cores) takes
+// over from the one-workgroup kernels (sequential-order sums, bit-replayed by the oracle).  Any n then works: the
+// leading dimension stays fl_reduction_geometry's threads*ept.  Tests lower it through the environment to hold the
+// blocked path to the reference's n = 1024 results.
+static int g_blocked_min_n = -1;
+static int blocked_min_n()
+{
+    if (g_blocked_min_n < 0) {
+        const char *e = getenv("FL_CHOL_BLOCKED_MIN_N");
+        g_blocked_min_n = (e && atoi(e) > 0) ? atoi(e) : 1025;
+    }
+    return g_blocked_min_n;
+}
+// sets the order from which fl_dposv_batched / fl_dpotri_batched use the blocked path; returns the previous value
+int fl_set_chol_blocked_min_n(int n)
+{
+    const int old = blocked_min_n();
+    if (n > 0) g_blocked_min_n = n;
+    return old;
+}
+// scratch from the stream-ordered allocator (released when the work queued before the free has finished)
+struct StreamScratch {
+    void *p = nullptr;
+    hipStream_t st;
+    StreamScratch(size_t bytes, hipStream_t s) : st(s)
+    {
+        if (hipMallocAsync(&p, bytes ? bytes : 8, st) != hipSuccess) {
+            p = nullptr;
+            (void)hipGetLastError();
+        }
+    }
+    ~StreamScratch() { if (p) (void)hipFreeAsync(p, st); }
+};
+
 int fl_dposv_batched(int batch, int n, double *A_dev, double *b_dev, int32_t *info_dev, void *stream)
 {
     if (!A_dev || !b_dev || batch <= 0 || n <= 0) return FL_ERR_INVALID_ARGUMENT;
     int threads = 0, ept = 0;
-    // one workgroup per matrix with its rows in registers: the register geometries only (beyond n = 4096
-    // fl_reduction_geometry answers with the vectors-in-HBM layout, which these kernels do not have)
-    if (n > 4096 || fl_reduction_geometry(n, &threads, &ept) != FL_OK) return FL_ERR_UNSUPPORTED_SIZE;
+    if (fl_reduction_geometry(n, &threads, &ept) != FL_OK) return FL_ERR_UNSUPPORTED_SIZE;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FL_ERR_NO_DEVICE;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (n >= blocked_min_n()) {
+        const size_t wsb = fl_chol_blocked_workspace_bytes(batch, n, 1);
+        StreamScratch ws(wsb, st), inf(info_dev ? 0 : sizeof(int32_t) * batch, st);
+        if (!ws.p || (!info_dev && !inf.p)) return FL_ERR_WORKSPACE;
+        return fl_dposv_blocked(batch, n, A_dev, threads * ept, b_dev, info_dev ? info_dev : static_cast<int32_t *>(inf.p),
+                                ws.p, wsb, st);
+    }
+    // one workgroup per matrix with its rows in registers: the register geometries only
+    if (n > 4096) return FL_ERR_UNSUPPORTED_SIZE;
     FL_GEO_DISPATCH(dposv_kernel, n, A_dev, b_dev, info_dev);
     return fl::launch_status();
 }
@@ -196,12 +238,18 @@ int fl_dpotri_batched(int batch, int n, double *A_dev, double *work_dev, int32_t
 {
     if (!A_dev || !work_dev || batch <= 0 || n <= 0) return FL_ERR_INVALID_ARGUMENT;
     int threads = 0, ept = 0;
-    // one workgroup per matrix with its rows in registers: the register geometries only (beyond n = 4096
-    // fl_reduction_geometry answers with the vectors-in-HBM layout, which these kernels do not have)
-    if (n > 4096 || fl_reduction_geometry(n, &threads, &ept) != FL_OK) return FL_ERR_UNSUPPORTED_SIZE;
+    if (fl_reduction_geometry(n, &threads, &ept) != FL_OK) return FL_ERR_UNSUPPORTED_SIZE;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FL_ERR_NO_DEVICE;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (n >= blocked_min_n()) { // work_dev ([batch][n][ld] by contract) holds X = L^{-1} as [batch][n][n]
+        const size_t wsb = fl_chol_blocked_workspace_bytes(batch, n, n);
+        StreamScratch ws(wsb, st), inf(info_dev ? 0 : sizeof(int32_t) * batch, st);
+        if (!ws.p || (!info_dev && !inf.p)) return FL_ERR_WORKSPACE;
+        return fl_dpotri_blocked(batch, n, A_dev, threads * ept, work_dev, info_dev ? info_dev : static_cast<int32_t *>(inf.p),
+                                 ws.p, wsb, st);
+    }
+    if (n > 4096) return FL_ERR_UNSUPPORTED_SIZE;
     FL_GEO_DISPATCH(dpotri_kernel, n, A_dev, work_dev, info_dev);
     return fl::launch_status();
 }

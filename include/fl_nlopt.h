@@ -167,6 +167,12 @@ int fl_newton_raphson_batched(int objective, int batch, int n, double *x_dev, co
  *                        work_dev: one more [batch][n][ld] buffer
  * info_dev[batch]: 0 or the index of the first non-positive pivot (then b / A are left as the reference leaves
  * them: b untouched, A partially factorised). */
+/* Size: n <= 1024 runs one workgroup per matrix with sums in sequential order (what the oracle replays bit for bit);
+ * from n = 1025 on -- any n, also beyond 4096 -- fl_dposv_batched / fl_dpotri_batched run a blocked right-looking
+ * Cholesky with many workgroups per matrix whose O(n^3) part is on the f64 matrix cores (csrc/fl_chol_blocked.hip);
+ * results then agree with LAPACK to rounding, not with the sequential kernel bit for bit.  fl_set_chol_blocked_min_n
+ * moves the threshold (returns the old one; also FL_CHOL_BLOCKED_MIN_N in the environment). */
+int fl_set_chol_blocked_min_n(int n);
 int fl_dposv_batched(int batch, int n, double *A_dev, double *b_dev, int32_t *info_dev, void *stream);
 int fl_dpotri_batched(int batch, int n, double *A_dev, double *work_dev, int32_t *info_dev, void *stream);
 /*   fl_dsysv_batched  <- My_dsysv  LinearAlgebra.f90:695-703 (LAPACK dsysv 'L'): symmetric INDEFINITE systems given by

@@ -125,3 +125,76 @@ def test_my_dsyev_symbol_matches_the_reference(n):
         if job == b"V":  # eigenvectors are defined up to sign (and rotation in near-degenerate pairs): residuals
             assert np.abs(A @ S - S * w[None, :]).max() <= max(50 * float(FIX[f"dsyev_V_resid_{n}"]), 1e-12 * norm)
             assert np.abs(S.T @ S - np.eye(n)).max() <= max(50 * float(FIX[f"dsyev_V_orth_{n}"]), 1e-12)
+
+
+# ---- the blocked multi-workgroup Cholesky (csrc/fl_chol_blocked.hip): default from n = 1025, forced here for smaller n
+@pytest.fixture
+def blocked_from_64():
+    FL = _fl()
+    old = FL.fl_set_chol_blocked_min_n(64)
+    yield
+    FL.fl_set_chol_blocked_min_n(old)
+
+
+@pytest.mark.parametrize("n", [64, 200, 1024])
+def test_blocked_cholesky_matches_the_reference(n, blocked_from_64):
+    """the same fixtures as the one-workgroup kernels above, through the blocked path (MFMA summation order: LAPACK
+    rounding, not bits)"""
+    NLO = _nlo()
+    dev = torch.device("cuda:0")
+    T, E = NLO.reduction_geometry(n)
+    ld = T * E
+    A, b = LC.spd_case(n)
+    Ad, bd = torch.tensor(_padded(A, ld), device=dev), torch.tensor(b[None, :].copy(), device=dev)
+    assert list(NLO.dposv(Ad, bd).cpu().numpy()) == [0]
+    x, ref = bd.cpu().numpy()[0], FIX[f"dposv_x_{n}"]
+    assert np.abs(x - ref).max() <= 5e-13 * max(1.0, np.abs(ref).max())
+    LC.compare_matrix(FIX, f"dposv_L_{n}", np.tril(Ad.cpu().numpy()[0, :, :n].T), n, rtol=5e-13)
+    Ad = torch.tensor(_padded(A, ld), device=dev)
+    assert list(NLO.dpotri(Ad).cpu().numpy()) == [0]
+    inv = Ad.cpu().numpy()[0, :, :n].T
+    assert np.abs(inv - inv.T).max() <= 1e-15 * np.abs(inv).max() * n
+    LC.compare_matrix(FIX, f"dpotri_{n}", np.tril(inv), n, rtol=5e-13)
+
+
+def test_blocked_cholesky_reports_info_and_leaves_b_alone(blocked_from_64):
+    NLO = _nlo()
+    dev = torch.device("cuda:0")
+    n = 64
+    T, E = NLO.reduction_geometry(n)
+    A, b = LC.nonspd_case(n)
+    A2, b2 = LC.spd_case(n)
+    Ap = np.concatenate([_padded(A, T * E), _padded(A2, T * E)])  # a batch: one failing, one fine
+    Ad, bd = torch.tensor(Ap, device=dev), torch.tensor(np.stack([b, b2]), device=dev)
+    info = NLO.dposv(Ad, bd).cpu().numpy()
+    assert list(info) == [int(FIX[f"nonspd_dposv_info_{n}"]), 0]
+    got = bd.cpu().numpy()
+    assert np.array_equal(got[0], b)  # untouched (LA.f90:718)
+    assert np.abs(got[1] - FIX[f"dposv_x_{n}"]).max() <= 5e-13
+
+
+@pytest.mark.parametrize("n,B", [(2048, 2), (5000, 1)])
+def test_blocked_cholesky_large_matrices_against_lapack(n, B):
+    """the default path from n = 1025 on, and beyond the 4096 of the register geometries; against numpy's LAPACK"""
+    NLO = _nlo()
+    dev = torch.device("cuda:0")
+    T, E = NLO.reduction_geometry(n)
+    ld = T * E
+    rng = np.random.default_rng(n)
+    Ap = np.zeros((B, n, ld))
+    As, bs = [], rng.uniform(-1, 1, (B, n))
+    for k in range(B):
+        G = rng.standard_normal((n, n))
+        A = G @ G.T / n + np.eye(n)
+        As.append(A)
+        Ap[k, :, :n] = A
+    Ad, bd = torch.tensor(Ap, device=dev), torch.tensor(bs, device=dev)
+    assert list(NLO.dposv(Ad, bd).cpu().numpy()) == [0] * B
+    for k in range(B):
+        ref = np.linalg.solve(As[k], bs[k])
+        assert np.abs(bd.cpu().numpy()[k] - ref).max() <= 1e-11 * np.abs(ref).max()
+    Ad = torch.tensor(Ap, device=dev)
+    assert list(NLO.dpotri(Ad).cpu().numpy()) == [0] * B
+    for k in range(B):
+        inv = Ad.cpu().numpy()[k, :, :n].T
+        assert np.abs(inv @ As[k] - np.eye(n)).max() <= 1e-10

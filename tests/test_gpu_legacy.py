@@ -670,17 +670,15 @@ def test_legacy_bfgs_beyond_the_register_path_n4500():
     assert cnt["f"] + cnt["f_fd"] == ref["nf"][0] and cnt["fd"] + cnt["f_fd"] == ref["ng"][0]
 
 
-def test_dense_and_two_loop_entry_points_refuse_dimensions_beyond_the_register_path():
-    """n > 4096: fl_reduction_geometry answers with the vectors-in-HBM layout (1024 threads), which the dense kernels
-    and the stand-alone recursion do not have: FL_ERR_UNSUPPORTED_SIZE (-2), nothing launched (round 1 fell through
-    to the 8 x 8 instantiation and returned FL_OK with garbage)."""
+def test_dsysv_and_two_loop_entry_points_refuse_dimensions_beyond_the_register_path():
+    """n > 4096: fl_reduction_geometry answers with the vectors-in-HBM layout (1024 threads), which the indefinite
+    solver and the stand-alone recursion do not have: FL_ERR_UNSUPPORTED_SIZE (-2), nothing launched (round 1 fell
+    through to the 8 x 8 instantiation and returned FL_OK with garbage)."""
     FL = _fl()
     dev = torch.device("cuda:0")
     n = 5000
     A = torch.zeros(1, 8, dtype=torch.float64, device=dev)  # never dereferenced
     info = torch.zeros(1, dtype=torch.int32, device=dev)
     p = lambda t: C.c_void_p(t.data_ptr())
-    assert FL.fl_dposv_batched(1, n, p(A), p(A), p(info), None) == -2
-    assert FL.fl_dpotri_batched(1, n, p(A), p(A), p(info), None) == -2
-    assert FL.fl_dsysv_batched(1, n, p(A), p(A), p(info), None) == -2
+    assert FL.fl_dsysv_batched(1, n, p(A), p(A), p(info), None) == -2  # (dposv / dpotri: blocked path, any n)
     assert FL.fl_lbfgs_two_loop_batched(1, n, 10, 9, p(A), p(A), p(A), p(A), None) == -2
