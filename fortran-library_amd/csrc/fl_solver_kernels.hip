@@ -295,7 +295,7 @@ template <int NW, int EPT> static int onchip_pairs_o(int obj)
 
 extern "C" {
 
-int fl_version(void) { return 101; }
+int fl_version(void) { return 102; }
 
 void fl_default_options(fl_options *o, int solver)
 {

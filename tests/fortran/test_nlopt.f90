@@ -1,53 +1,50 @@
-!Fortran smoke test of the drop-in module, mirroring the optimiser section of the reference's
-!test/test.f90:330-413 (quartic sum x^4, dim = 10; "Correct routines should print close to 0").
-!Deterministic start x_i = 0.1 i instead of the reference's clock-seeded random_number(x).
-module quartic
+!Fortran smoke test of the drop-in module: every public routine of `use FortranLibrary` called the way the
+!reference's own test program calls them (test/test.f90:330-478: all solvers, with and without f_fd / fdd, both line
+!searches, the augmented Lagrangian on the unit sphere; "correct routines should print close to 0"), on an objective
+!of this repository: the anharmonic bowl  f(x) = sum_i ( i x_i^2 / 2 + x_i^4 / 4 ),  minimum at x = 0.
+!Deterministic start x_i = 0.1 i (the reference seeds random_number from the clock).
+module bowl
     implicit none
 contains
     subroutine f(fx,x,dim)
         real*8,intent(out)::fx
         integer,intent(in)::dim
         real*8,dimension(dim),intent(in)::x
-        integer::i
-        fx=0d0
-        do i=1,dim
-            fx=fx+x(i)**4
-        end do
+        fx=sum(weights(dim)*x*x)/2d0+sum(x**4)/4d0
     end subroutine f
     subroutine fd(fdx,x,dim)
         integer,intent(in)::dim
         real*8,dimension(dim),intent(out)::fdx
         real*8,dimension(dim),intent(in)::x
-        integer::i
-        do i=1,dim
-            fdx(i)=4d0*x(i)**3
-        end do
+        fdx=weights(dim)*x+x**3
     end subroutine fd
     integer function f_fd(fx,fdx,x,dim)
         integer,intent(in)::dim
         real*8,intent(out)::fx
         real*8,dimension(dim),intent(out)::fdx
         real*8,dimension(dim),intent(in)::x
-        integer::i
-        fx=0d0
-        do i=1,dim
-            fx=fx+x(i)**4
-            fdx(i)=4d0*x(i)**3
-        end do
+        call f(fx,x,dim)
+        call fd(fdx,x,dim)
         f_fd=0
     end function f_fd
     integer function fdd(fddx,x,N)
         integer,intent(in)::N
         real*8,dimension(N,N),intent(out)::fddx
         real*8,dimension(N),intent(in)::x
+        real*8,dimension(N)::w
         integer::i
+        w=weights(N)
         fddx=0d0
-        do i=1,N
-            fddx(i,i)=12d0*x(i)*x(i)
-        end do
+        forall(i=1:N) fddx(i,i)=w(i)+3d0*x(i)*x(i)
         fdd=0
     end function fdd
-    !unit-sphere equality constraint like the reference's test (test/test.f90:677-695)
+    function weights(N)
+        integer,intent(in)::N
+        real*8,dimension(N)::weights
+        integer::i
+        weights=[(dble(i),i=1,N)]
+    end function weights
+    !one equality constraint, the unit sphere: c(x) = x.x - 1
     subroutine c(cx,x,M,N)
         integer,intent(in)::M,N
         real*8,dimension(M),intent(out)::cx
@@ -60,11 +57,11 @@ contains
         real*8,dimension(N),intent(in)::x
         cdx(:,1)=2d0*x
     end subroutine cd
-end module quartic
+end module bowl
 
 program main
     use FortranLibrary
-    use quartic
+    use bowl
     implicit none
     integer,parameter::dim=10
     integer::i

@@ -11,7 +11,7 @@ build() {
   for src in fl_solver_kernels fl_aux_kernels fl_bfgs_gemm fl_dense_kernels; do
     /opt/rocm/bin/hipcc $FLAGS $flags -c $P/csrc/$src.hip -o $d/$src.o 2>$d/$src.err || { echo "FAILED $name $src"; grep error $d/$src.err | head -3; }
   done
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $P/lib/variants/libFL_$name.so $d/*.o $P/csrc/fl_rci.o $P/csrc/fl_general.o $P/csrc/fl_linalg.o -ldl 2>$d/link.err || { echo "LINK FAILED $name"; head -3 $d/link.err; }
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $P/lib/variants/libFL_$name.so $d/*.o $P/csrc/fl_rci.o $P/csrc/fl_blas_kernels.o $P/csrc/fl_chol_blocked.o $P/csrc/fl_general.o $P/csrc/fl_linalg.o 2>$d/link.err || { echo "LINK FAILED $name"; head -3 $d/link.err; }
 }
 for spec in "$@"; do
   build "${spec%%:*}" "${spec#*:}" &
