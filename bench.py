@@ -429,6 +429,19 @@ def main():
             "x_within_1e-8_fraction": float((xerr_t <= 1e-8).mean()),
             "x_within_1e-8_fraction_where_both_met_the_gradient_test": float((xerr_t[both] <= 1e-8).mean()) if both.any() else None,
             "f_rel_err_max": float(ferr_t.max()), "x_err_max": float(xerr_t.max())}
+        if objective == NLO.DIAGQUAD:  # the exact minimiser is known here (x* = b / d): how far is either side from it?
+            xstar = bs[:SB] / ds[:SB]
+            nrm = np.maximum(1.0, np.linalg.norm(xstar, axis=1))
+            res["parity"]["tight"]["gpu_to_exact_minimiser_err_max"] = float((np.linalg.norm(gxt - xstar, axis=1) / nrm).max())
+            res["parity"]["tight"]["cpu_reference_order_to_exact_minimiser_err_max"] = float(
+                (np.linalg.norm(rt["x"] - xstar, axis=1) / nrm).max())
+            res["parity"]["tight"]["note"] = (
+                "no problem of this family (kappa up to 1e3, |f*| ~ 10..100) reaches ||g|| < 1e-9 on either side: an "
+                "objective-value line search in fp64 stalls near ||g|| ~ 1e-7 and both stop on MinStepLength / MaxIteration "
+                "(SURVEY.md section 6).  The reference's own answer is therefore defined to ~1e-7 in x -- see the two "
+                "distances to the exact minimiser b/d -- and GPU and CPU agree to that level; where the gradient test IS "
+                "attainable (kappa <= 100) the 1e-8 bar holds: tests/test_gpu_parity.py::"
+                "test_north_star_tolerance_vs_reference_summation")
         res["parity"]["ok"] = bool(ferr.max() <= 1e-10 and bit["x"] and bit["f"] and bit["iterations"])
         res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
 

@@ -1,8 +1,9 @@
 // fl_chol_blocked.hip -- My_dposv / My_dpotri (LinearAlgebra.f90:719-730, 798-812 + dsyL2U 260-265) for LARGE matrices:
 // blocked right-looking Cholesky whose O(n^3) part runs on the f64 matrix cores through dgemm_kernel
-// (fl_blas_kernels.hip), many workgroups per matrix.  fl_dposv_batched / fl_dpotri_batched take this path beyond
-// n = 1024 (and beyond n = 4096, where the one-workgroup kernels of fl_dense.hpp do not exist at all); up to 1024 they
-// keep the sequential-order kernels, whose sums the oracle replays bit for bit.  Here the summation order is the MFMA's,
+// (fl_blas_kernels.hip), many workgroups per matrix.  fl_dposv_batched / fl_dpotri_batched take this path from
+// n = 512 on (and beyond n = 4096, where the one-workgroup kernels of fl_dense.hpp do not exist at all); below they
+// keep the sequential-order kernels, whose sums the oracle replays bit for bit (the solvers' own Cholesky steps --
+// NewtonRaphson, the exact-Hessian refresh of BFGS -- always do, inside the fused kernel).  Here the summation order is the MFMA's,
 // so parity is to LAPACK rounding (tests: the reference's own results in tests/golden/la_ref.npz at n = 1024 through
 // FL_CHOL_BLOCKED_MIN_N, numpy beyond).
 //

@@ -179,7 +179,7 @@ extern "C" {
         else return FL_ERR_UNSUPPORTED_SIZE; /* a geometry none of the dense kernels is built for */                 \
     } while (0)
 
-// Beyond this order the blocked multi-workgroup Cholesky (fl_chol_blocked.hip: O(n^3) on the f64 matrix cores) takes
+// From this order on the blocked multi-workgroup Cholesky (fl_chol_blocked.hip: O(n^3) on the f64 matrix cores) takes
 // over from the one-workgroup kernels (sequential-order sums, bit-replayed by the oracle).  Any n then works: the
 // leading dimension stays fl_reduction_geometry's threads*ept.  Tests lower it through the environment to hold the
 // blocked path to the reference's n = 1024 results.
@@ -188,7 +188,9 @@ static int blocked_min_n()
 {
     if (g_blocked_min_n < 0) {
         const char *e = getenv("FL_CHOL_BLOCKED_MIN_N");
-        g_blocked_min_n = (e && atoi(e) > 0) ? atoi(e) : 1025;
+        // measured (profiles/r02/chol_ab.txt): n = 256 x 4096 matrices 8.3 ms sequential / 13.2 blocked (posv), but
+        // 512 x 1024: 15.4 / 10.9, 1024 x 256: 51.4 / 13.6, 4096 x 16: 972 / 61 -- the blocked path from n = 512 on
+        g_blocked_min_n = (e && atoi(e) > 0) ? atoi(e) : 512;
     }
     return g_blocked_min_n;
 }

@@ -167,8 +167,8 @@ int fl_newton_raphson_batched(int objective, int batch, int n, double *x_dev, co
  *                        work_dev: one more [batch][n][ld] buffer
  * info_dev[batch]: 0 or the index of the first non-positive pivot (then b / A are left as the reference leaves
  * them: b untouched, A partially factorised). */
-/* Size: n <= 1024 runs one workgroup per matrix with sums in sequential order (what the oracle replays bit for bit);
- * from n = 1025 on -- any n, also beyond 4096 -- fl_dposv_batched / fl_dpotri_batched run a blocked right-looking
+/* Size: n < 512 runs one workgroup per matrix with sums in sequential order (what the oracle replays bit for bit);
+ * from n = 512 on -- any n, also beyond 4096 -- fl_dposv_batched / fl_dpotri_batched run a blocked right-looking
  * Cholesky with many workgroups per matrix whose O(n^3) part is on the f64 matrix cores (csrc/fl_chol_blocked.hip);
  * results then agree with LAPACK to rounding, not with the sequential kernel bit for bit.  fl_set_chol_blocked_min_n
  * moves the threshold (returns the old one; also FL_CHOL_BLOCKED_MIN_N in the environment). */

@@ -55,15 +55,16 @@ def test_dposv_and_dpotri_kernels_match_the_reference(n):
     info = NLO.dposv(Ad, bd).cpu().numpy()
     assert list(info) == [int(FIX[f"dposv_info_{n}"])] == [0]
     x, ref = bd.cpu().numpy()[0], FIX[f"dposv_x_{n}"]
-    assert np.abs(x - ref).max() <= 2e-13 * max(1.0, np.abs(ref).max())
+    tol = 2e-13 if n < 512 else 5e-13  # from n = 512 on: the blocked path (MFMA summation order)
+    assert np.abs(x - ref).max() <= tol * max(1.0, np.abs(ref).max())
     L = np.tril(Ad.cpu().numpy()[0, :, :n].T)  # A harvests the Cholesky factor (LA.f90:717)
-    LC.compare_matrix(FIX, f"dposv_L_{n}", L, n, rtol=2e-13)
+    LC.compare_matrix(FIX, f"dposv_L_{n}", L, n, rtol=tol)
     Ad = torch.tensor(_padded(A, ld), device=dev)
     info = NLO.dpotri(Ad).cpu().numpy()
     assert list(info) == [int(FIX[f"dpotri_info_{n}"])] == [0]
     inv = Ad.cpu().numpy()[0, :, :n].T
-    assert np.array_equal(inv, inv.T)  # dsyL2U: both triangles
-    LC.compare_matrix(FIX, f"dpotri_{n}", np.tril(inv), n, rtol=2e-13)
+    assert np.abs(inv - inv.T).max() <= (0.0 if n < 512 else 1e-15 * n * np.abs(inv).max())  # dsyL2U: both triangles
+    LC.compare_matrix(FIX, f"dpotri_{n}", np.tril(inv), n, rtol=2e-13 if n < 512 else 5e-13)
 
 
 @pytest.mark.parametrize("n", LC.NONSPD_SIZES)
@@ -127,7 +128,7 @@ def test_my_dsyev_symbol_matches_the_reference(n):
             assert np.abs(S.T @ S - np.eye(n)).max() <= max(50 * float(FIX[f"dsyev_V_orth_{n}"]), 1e-12)
 
 
-# ---- the blocked multi-workgroup Cholesky (csrc/fl_chol_blocked.hip): default from n = 1025, forced here for smaller n
+# ---- the blocked multi-workgroup Cholesky (csrc/fl_chol_blocked.hip): default from n = 512, forced here for smaller n
 @pytest.fixture
 def blocked_from_64():
     FL = _fl()
@@ -175,7 +176,7 @@ def test_blocked_cholesky_reports_info_and_leaves_b_alone(blocked_from_64):
 
 @pytest.mark.parametrize("n,B", [(2048, 2), (5000, 1)])
 def test_blocked_cholesky_large_matrices_against_lapack(n, B):
-    """the default path from n = 1025 on, and beyond the 4096 of the register geometries; against numpy's LAPACK"""
+    """the default path from n = 512 on, and beyond the 4096 of the register geometries; against numpy's LAPACK"""
     NLO = _nlo()
     dev = torch.device("cuda:0")
     T, E = NLO.reduction_geometry(n)
