@@ -229,10 +229,11 @@ def BFGS(objective, x, d=None, b=None, workspace_=None, options=None, **kw):
 def AugmentedLagrangian(objective, x, M, d=None, b=None, UnconstrainedSolver="LBFGS", lambda0=None, miu0=1.0,
                         workspace_=None, options=None, **kw):
     """Batched augmented Lagrangian with M block-sphere equality constraints (reference: subroutine
-    AugmentedLagrangian, NO.f90:2005-2241).  UnconstrainedSolver: 'LBFGS' | 'ConjugateGradient'.
-    lambda0: optional [batch, M] tensor, updated in place (returned as out['lambda'])."""
+    AugmentedLagrangian, NO.f90:2005-2241).  UnconstrainedSolver: 'LBFGS' | 'ConjugateGradient' | 'BFGS' (pass
+    ExactStep=0: the quasi-Newton branch).  lambda0: optional [batch, M] tensor, updated in place (returned as
+    out['lambda'])."""
     import torch
-    solvers = {"LBFGS": LBFGS_, "ConjugateGradient": CG}
+    solvers = {"LBFGS": LBFGS_, "ConjugateGradient": CG, "BFGS": BFGS_}
     if UnconstrainedSolver not in solvers:  # reference: "Program abort: unsupported unconstrained solver" (NO.f90:2186)
         raise ValueError("unsupported unconstrained solver on the device path: " + str(UnconstrainedSolver))
     solver = solvers[UnconstrainedSolver]
@@ -241,8 +242,12 @@ def AugmentedLagrangian(objective, x, M, d=None, b=None, UnconstrainedSolver="LB
     lam = lambda0 if lambda0 is not None else torch.zeros(B, M, dtype=torch.float64, device=x.device)
     ws = workspace_
     if ws is None:
-        ws = workspace(B, n, o.memory, x.device) if solver == LBFGS_ else torch.empty(1, dtype=torch.float64,
-                                                                                      device=x.device)
+        if solver == LBFGS_:
+            ws = workspace(B, n, o.memory, x.device)
+        elif solver == BFGS_:
+            ws = bfgs_workspace(B, n, x.device, o)
+        else:
+            ws = torch.empty(1, dtype=torch.float64, device=x.device)
     out["outer"] = torch.empty(B, dtype=torch.int32, device=x.device)
     out["cnorm2"] = torch.empty(B, dtype=torch.float64, device=x.device)
     _check(FL.fl_augmented_lagrangian_batched(solver, objective, B, n, M, _ptr(x), _ptr(d), _ptr(b), _ptr(lam),

@@ -984,6 +984,10 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
             recent = -1;
             lrec = -1;
             cnt = 0;
+            main_it = 0; // BFGS: a new call of the inner solver builds its inverse Hessian from H = a I again
+            h_valid = 0;
+            ndef = 0;
+            h_ident = 0;
             phase = PH_INIT;
             return FL_REQ_F | FL_REQ_G | FL_REQ_NOMOVE;
         } else {

@@ -134,8 +134,9 @@ static hipError_t launch_k(const SolveArgs &A, hipStream_t st)
 }
 template <int NW, int EPT, int OBJ> static hipError_t launch_m(int method, int aug, const SolveArgs &A, hipStream_t st)
 {
-    if (aug) { // augmented Lagrangian around L-BFGS or CG (NO.f90:2150-2185)
+    if (aug) { // augmented Lagrangian around L-BFGS, CG (NO.f90:2150-2185) or quasi-Newton BFGS (2131-2148, ExactStep <= 0)
         if (method == FL_SOLVER_CG) return launch_k<NW, EPT, OBJ, FL_SOLVER_CG, 1>(A, st);
+        if (method == FL_SOLVER_BFGS) return launch_k<NW, EPT, OBJ, FL_SOLVER_BFGS, 1, 0>(A, st);
         return launch_k<NW, EPT, OBJ, FL_SOLVER_LBFGS, 1>(A, st);
     }
     switch (method) {
@@ -245,7 +246,10 @@ static int solve(int method, int objective, int batch, int n, double *x, const d
     if (aug) {
         if (aug->m < 1 || aug->m > FL_MAX_CONSTRAINTS || n % aug->m != 0 || !aug->lambda)
             return FL_ERR_INVALID_ARGUMENT;
-        if (method != FL_SOLVER_LBFGS && method != FL_SOLVER_CG) return FL_ERR_INVALID_ARGUMENT;
+        if (method != FL_SOLVER_LBFGS && method != FL_SOLVER_CG && method != FL_SOLVER_BFGS) return FL_ERR_INVALID_ARGUMENT;
+        // inner BFGS: the quasi-Newton branch only (the reference's default ExactStep = 20 would take numerical
+        // Hessians of L from MKL's djacobi when no fdd / cdd is passed, NO.f90:2131-2148)
+        if (method == FL_SOLVER_BFGS && opt->exact_step > 0) return FL_ERR_INVALID_ARGUMENT;
         A.aug_m = aug->m;
         A.miu0 = aug->miu0;
         A.lambda = aug->lambda;

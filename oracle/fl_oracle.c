@@ -1256,6 +1256,10 @@ static int al_L_Ld(double *Lx, double *Ldx, const double *x, int n, void *vp) /*
 
 /* AugmentedLagrangian, NO.f90:2005-2241 (LBFGS case 2150-2167, CG 2168-2185,
  * BFGS without fdd/cdd 2131-2148).  st->nf/ng count USER f/fd calls. */
+/* update form of the inner BFGS (0 = as written; 1 / 100+J = what the kernels evaluate): set once before a run */
+static int al_bfgs_form = 0;
+void flo_set_auglag_bfgs_form(int form) { al_bfgs_form = form; }
+
 void flo_augmented_lagrangian(flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, flo_c_t c, flo_cd_t cd, double *x, int n,
                               int m, int solver, double *lambda, double miu0, const flo_opts *o, void *ctx,
                               flo_stats *st, int *outer_iters, double *cnorm2)
@@ -1285,7 +1289,7 @@ void flo_augmented_lagrangian(flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, flo_c_t c,
         else if (solver == 2)
             flo_conjugate_gradient(al_L, al_Ld, al_L_Ld, x, n, o, &A, &in);
         else
-            flo_bfgs(al_L, al_Ld, al_L_Ld, NULL, x, n, o, 0, &A, &in);
+            flo_bfgs(al_L, al_Ld, al_L_Ld, NULL, x, n, o, al_bfgs_form, &A, &in);
         st->iters += in.iters;
         st->f = in.f;
         st->gg = in.gg;

@@ -570,3 +570,40 @@ def test_augmented_lagrangian_batch_with_the_callers_constraints_by_reverse_comm
     # ... and the fused kernel with its compiled-in block spheres gives the same (three ways to the same bits)
     fused = _gpu_auglag(solver_name, kind, x0, m, d, b, **kw)
     assert np.array_equal(fused["x"].view(np.uint64), o["x"].view(np.uint64))
+
+
+@pytest.mark.parametrize("kind,n,m,kw", [
+    (O.QUARTIC, 10, 1, {"Precision": 1e-8}),                     # the reference's own test problem (test/test.f90:452-478)
+    (O.DIAGQUAD, 64, 8, {"Precision": 1e-8}),
+    (O.ROSENBROCK, 96, 3, {"Precision": 1e-7}),
+    (O.DIAGQUAD, 1100, 4, {"Precision": 1e-6, "MaxIteration": 30}),  # n > 1024: deferred rank-2 updates inside the AL
+])
+def test_augmented_lagrangian_with_bfgs_inner_solver_bitexact(kind, n, m, kw):
+    """UnconstrainedSolver = 'BFGS' (NO.f90:2131-2148) with ExactStep = 0: every outer round is a fresh quasi-Newton
+    BFGS on the augmented Lagrangian (H rebuilt from a I).  Oracle: flo_augmented_lagrangian around flo_bfgs in the
+    update form the kernels evaluate (rank-2; deferred beyond n = 1024)."""
+    NLO = _nlo()
+    rng = np.random.default_rng(11 * n + m)
+    B = 3
+    i = np.arange(1, n + 1).astype(float)
+    x0 = 0.1 + 0.05 * np.cos(i)[None, :] + 0.01 * rng.standard_normal((B, n))
+    if kind == O.QUARTIC:
+        x0 = rng.random((B, n))
+    d = b = None
+    if kind == O.DIAGQUAD:
+        d, b = _quads(B, n, 2.0, 10.0, 5)
+    g = _gpu_auglag("BFGS", kind, x0, m, d, b, ExactStep=0, **kw)
+    T, E = NLO.reduction_geometry(n)
+    O.lib().flo_set_auglag_bfgs_form(108 if T * E >= 2048 else 1)
+    try:
+        oo = _oracle_opts(O.BFGS, kw)
+        oo.exact_step = 0
+        o = O.auglag_batch(O.BFGS, kind, x0, m, d=d, b=b, opts=oo, sum_mode=O.TREE, threads=T, ept=E)
+    finally:
+        O.lib().flo_set_auglag_bfgs_form(0)
+    assert np.array_equal(g["outer"], o["outer"]), (g["outer"], o["outer"])
+    assert np.array_equal(g["iters"], o["iters"]), (g["iters"], o["iters"])
+    assert np.array_equal(g["nf"], o["nf"]) and np.array_equal(g["ng"], o["ng"])
+    assert np.array_equal(g["x"].view(np.uint64), o["x"].view(np.uint64))
+    assert np.array_equal(g["lambda"].view(np.uint64), o["lam"].view(np.uint64))
+    assert np.array_equal(g["cnorm2"].view(np.uint64), o["cnorm2"].view(np.uint64))
