@@ -59,10 +59,11 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(int n, int k0, double *A
         __syncthreads();
         if (tid < CNB && tid >= j) S[j][tid] = (tid == j) ? ajj : S[j][tid] / ajj;
         __syncthreads();
-        // trailing columns c > j of the block: S[c][r] -= L[r][j] L[c][j], r >= c
-        for (int e = tid; e < CNB * CNB; e += 256) {
-            const int c = e / CNB, r = e - c * CNB;
-            if (c > j && r >= c && c < nb) S[c][r] = S[c][r] - S[j][r] * S[j][c];
+        // trailing columns c > j of the block: S[c][r] -= L[r][j] L[c][j], r >= c (only the (nb-j-1)^2 square is visited)
+        const int mrest = nb - j - 1;
+        for (int e = tid; e < mrest * mrest; e += 256) {
+            const int c = j + 1 + e / mrest, r = j + 1 + e % mrest;
+            if (r >= c) S[c][r] = S[c][r] - S[j][r] * S[j][c];
         }
         __syncthreads();
     }
@@ -73,16 +74,35 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(int n, int k0, double *A
         if (r < nb && c < nb && r >= c) A[(size_t)c * lda + r] = S[c][r];
     }
     if (bad) return;
-    // W = L^{-1}: column c by forward substitution, one thread per column
-    if (tid < CNB) {
-        const int c = tid;
-        for (int i = 0; i < CNB; ++i) {
-            double t = (i == c) ? 1.0 : 0.0;
-            for (int k = c; k < i; ++k) t = t - S[k][i] * Wt[c][k];
-            Wt[c][i] = (i >= c) ? t / S[i][i] : 0.0;
-        }
+    // W = L^{-1} by doubling: the inverse of [A 0; B C] is [A^-1 0; -C^-1 B A^-1  C^-1].  Diagonal 1 x 1 blocks first,
+    // then pairs of adjacent s x s blocks for s = 1, 2, 4, ..., 32: T = B A^-1 and X = -C^-1 T are s x s products over
+    // the whole workgroup (a thread-per-column substitution would be a 2000-step dependent chain of LDS reads).
+    for (int e = tid; e < CNB * CNB; e += 256) {
+        const int c = e / CNB, r = e - c * CNB;
+        Wt[c][r] = (r == c) ? 1.0 / S[c][c] : 0.0;
     }
     __syncthreads();
+    __shared__ double Tm[CNB][CNB / 2 + 1]; // T = B A^-1 of every pair of the level: Tm[row of B][column within the pair]
+    for (int sz = 1; sz < CNB; sz *= 2) {
+        // pair p covers rows/cols [2 p sz, 2 p sz + 2 sz): A = first half, C = second half, B = L(second, first)
+        const int npairs = CNB / (2 * sz), per = sz * sz;
+        for (int e = tid; e < npairs * per; e += 256) {
+            const int pr = e / per, q = e - pr * per, rr = q / sz, cc = q - rr * sz;
+            const int a0 = 2 * pr * sz, c0 = a0 + sz;
+            double t = 0.0;
+            for (int k = cc; k < sz; ++k) t += S[a0 + k][c0 + rr] * Wt[a0 + cc][a0 + k]; // B(rr,k) * Ainv(k,cc)
+            Tm[c0 + rr][cc] = t;
+        }
+        __syncthreads();
+        for (int e = tid; e < npairs * per; e += 256) {
+            const int pr = e / per, q = e - pr * per, rr = q / sz, cc = q - rr * sz;
+            const int a0 = 2 * pr * sz, c0 = a0 + sz;
+            double t = 0.0;
+            for (int k = 0; k <= rr; ++k) t += Wt[c0 + k][c0 + rr] * Tm[c0 + k][cc]; // Cinv(rr,k) * T(k,cc)
+            Wt[a0 + cc][c0 + rr] = -t;
+        }
+        __syncthreads();
+    }
     for (int e = tid; e < CNB * CNB; e += 256) {
         const int c = e / CNB, r = e - c * CNB;
         W[(size_t)c * CNB + r] = Wt[c][r];
