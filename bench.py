@@ -27,7 +27,7 @@ HIP events on the launch stream):
   * achieved  = traffic / kernel time (when there is no valid record: the model below / kernel time),
                 frac = achieved / 8 TB/s -- a bound that binds: <= 1 by construction;
   * model     = the bytes the shipped kernel asks the L2 for: with C pairs of the ring on the chip
-                (fl_lbfgs_onchip_pairs) an iteration loads max(0,2(cnt-C)) + max(0,2(cnt-C-1)) rows and
+                (fl_lbfgs_onchip_pairs) an iteration loads max(0,2(cnt-C)) + max(0,2(cnt-C-2)) rows and
                 stores 2.  traffic_over_model is what of it crossed to the memory side: 1 - (L2 hits), the rows
                 around the turn-around of the recursion being re-read within a few microseconds; > 1 would be
                 re-fetching;
@@ -252,7 +252,7 @@ def main():
     C_on = NLO.lbfgs_onchip_pairs(objective, n)
     algo_bytes = float(sum_over_two_loops(lambda c: (4 * c + 2) * 8 * n))
     writes = 2 if m > C_on else 0
-    model_bytes = float(sum_over_two_loops(lambda c: (max(0, 2 * (c - C_on)) + max(0, 2 * (c - C_on - 1)) + writes)
+    model_bytes = float(sum_over_two_loops(lambda c: (max(0, 2 * (c - C_on)) + max(0, 2 * (c - C_on - 2)) + writes)
                                            * row_bytes))
     kern_ms = sum(a.elapsed_time(bb) for a, bb in ev) / len(ev)
     status = out["status"].cpu().numpy()

@@ -1124,8 +1124,8 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
         };
         // Row buffers: the pairs that have to be fetched alternate between B and A, starting with B at j = J0 (the
         // first pair behind the ones the way down has in registers: the new pair sv, yv and the register pairs).  The
-        // oldest pair is used twice in a row (last step down, first step up) and is not fetched again; every other
-        // row is in flight one step ahead of its use.  On the way up the pairs j >= L come through the buffers
+        // two oldest pairs are still in the two buffers at the turn-around (last two steps down, first two steps up)
+        // and are not fetched again; every other row is in flight one step ahead of its use.  On the way up the pairs j >= L come through the buffers
         // (j = 0 too when no pair is kept in registers), the register pairs last.
         constexpr int J0 = RP > 1 ? RP : 1, L = RP;
         if (cnt > J0) fetch(J0, sB, yB);
@@ -1146,13 +1146,18 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
         __syncthreads(); // alpha_s written by thread 0 is visible (NW == 1 has no reduction barrier)
         int j = cnt - 1;
         if (RP == 0 && cnt == 1) fetch(0, sA, yA);
+        // the pair BEFORE the oldest went through the other buffer on the way down and nothing has overwritten it:
+        // the two oldest pairs are both used twice and fetched once
+        bool prev_resident = (j - 1 >= J0);
         if (j >= L && (((j - J0) & 1) != 0)) { // the top pair waits in A
-            if (j - 1 >= L) fetch(j - 1, sB, yB);
+            if (j - 1 >= L && !prev_resident) fetch(j - 1, sB, yB);
+            prev_resident = false;
             upw(j, sA, yA);
             --j;
         }
         for (; j >= L; j -= 2) { // j: resident / prefetched in B
-            if (j - 1 >= L) fetch(j - 1, sA, yA);
+            if (j - 1 >= L && !prev_resident) fetch(j - 1, sA, yA);
+            prev_resident = false;
             upw(j, sB, yB);
             if (j - 1 >= L) {
                 if (j - 2 >= L) fetch(j - 2, sB, yB);

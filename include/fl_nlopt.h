@@ -105,8 +105,8 @@ int fl_reduction_geometry(int n, int *threads, int *ept);
 
 /* The fused L-BFGS kernel keeps the newest pairs of its (s, y) ring on the chip (registers, then an LDS ring); this
  * returns how many for a built-in objective and dimension n (0 beyond n = 4096).  With C of them on the chip an
- * iteration with cnt pairs in the ring fetches max(0, 2(cnt-C)) + max(0, 2(cnt-C-1)) rows of 8*npad bytes from HBM
- * (the oldest pair is used twice in a row and fetched once) and stores 2 -- the minimum-traffic model bench.py
+ * iteration with cnt pairs in the ring fetches max(0, 2(cnt-C)) + max(0, 2(cnt-C-2)) rows of 8*npad bytes from HBM
+ * (the two oldest pairs are still in the row buffers at the turn-around and fetched once) and stores 2 -- the model bench.py
  * prints next to the measured traffic. */
 int fl_lbfgs_onchip_pairs(int objective, int n);
 
