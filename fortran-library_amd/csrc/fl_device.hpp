@@ -463,6 +463,11 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
     // LEAN: what else is shed where 256 VGPRs per wave are short (dense kernels at 8 elements per thread; every
     // 512-thread augmented-Lagrangian kernel): d, b of the diagonal quadratic are re-read per evaluation.
     static constexpr bool LEAN = PARK || (AUG && NW >= 8);
+    // fused kernels without constraints: g.g is reduced once per line search instead of once per trial
+#ifndef FL_LAZY_GG
+#define FL_LAZY_GG 1
+#endif
+    static constexpr bool LAZY_GG = FL_LAZY_GG && !AUG && OBJ != FL_OBJ_EXTERNAL;
 #ifndef FL_UNI_LEAN
 #define FL_UNI_LEAN 2
 #endif
@@ -615,6 +620,13 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
             R.run(q2);
             gp = uni(q2[0]);
             ggo = uni(q2[1]);
+        } else if constexpr (LAZY_GG) {
+            // g.g is wanted once per line search (the convergence test after it), not per trial: advance() reduces it
+            // when the search has ended -- 15 of the ~94 f64 operations of a trial
+            double r3[3] = {r[0], r[1], dot_part<EPT>(g, p)};
+            R.run(r3);
+            f = uni(Obj::combine(r3[0], r3[1]));
+            gp = uni(r3[2]);
         } else {
             r[2] = dot_part<EPT>(g, p);
             r[3] = dot_part<EPT>(g, g);
@@ -623,6 +635,12 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
             gp = uni(r[2]);
             ggo = uni(r[3]);
         }
+    }
+    __device__ __forceinline__ double reduce_gg()
+    {
+        double q[1] = {dot_part<EPT>(g, g)};
+        R.run(q);
+        return uni(q[0]);
     }
 
     // Reverse communication with the CALLER's constraints (AugmentedLagrangian's c, cd callbacks, NO.f90:1928-1934):
@@ -673,14 +691,18 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
         ng += (pending & FL_REQ_G) ? 1 : 0;
         int rq;
         if (phase == PH_INIT) {
+            if constexpr (LAZY_GG) gg_new = reduce_gg();
             rq = after_init(fv, gg_new);
         } else if (HESS_RCI && phase == PH_HESS) { // the caller has written the Hessian it was asked for
             rq = (hess_stage == 0) ? GO_INIT_REST : GO_DIRECTION;
         } else {
-            gg = gg_new;
+            if constexpr (!LAZY_GG) gg = gg_new;
             rq = __builtin_amdgcn_readfirstlane(ls.step(fv, pv));
             ls.template uniformize<UNI_LEVEL>();
-            if (rq == 0) rq = after_linesearch();
+            if (rq == 0) {
+                if constexpr (LAZY_GG) gg = reduce_gg(); // x, g are those of the accepted point (the last evaluation)
+                rq = after_linesearch();
+            }
         }
         bool initial = false, refreshed = false;
         if (rq == GO_INIT_REST) {
