@@ -23,6 +23,7 @@
 #include <functional>
 #include <string>
 #include <new>
+#include <algorithm>
 #include <vector>
 
 namespace fl {
@@ -493,48 +494,51 @@ static int legacy_solve(int solver, const char *name, const HostObjective &ob, d
         std::fprintf(stderr, "FortranLibrary(MI355X) %s: cannot run on the device (error %d); x is unchanged\n", name, rc);
         return rc;
     }
-    double *xd = nullptr, *fdv = nullptr, *gd = nullptr;
-    int32_t *rqd = nullptr;
-    std::vector<double> g(n), hess;
-    double fx = 0.0;
-    int32_t rq = 0, status = FL_STATUS_MAXIT;
-    bool ok = hipMalloc((void **)&xd, sizeof(double) * n) == hipSuccess &&
-              hipMalloc((void **)&fdv, sizeof(double)) == hipSuccess &&
-              hipMalloc((void **)&gd, sizeof(double) * n) == hipSuccess &&
-              hipMalloc((void **)&rqd, sizeof(int32_t)) == hipSuccess;
-    ok = ok && hipMemcpy(xd, x, sizeof(double) * n, hipMemcpyHostToDevice) == hipSuccess;
+    // The mailbox between the step kernel and the host callbacks: x, f'(x), f and the request live in ONE block of
+    // pinned host memory that is mapped into the device's address space.  The kernel reads the evaluations from it and
+    // writes the next trial point and request into it directly; the host only synchronises the stream.  (Round 1 moved
+    // them with three or four pageable hipMemcpy per trial -- most of the time of a one-problem solve.)
+    double *mail = nullptr, *mail_dev = nullptr;
+    std::vector<double> hess;
+    int32_t status = FL_STATUS_MAXIT;
+    const size_t mail_doubles = 2 * (size_t)n + 2;
+    bool ok = hipHostMalloc((void **)&mail, sizeof(double) * mail_doubles, hipHostMallocMapped) == hipSuccess &&
+              hipHostGetDevicePointer((void **)&mail_dev, mail, 0) == hipSuccess;
+    double *xm = mail, *gm = mail + n, *fm = mail + 2 * n;           // host views
+    volatile int32_t *rqm = reinterpret_cast<volatile int32_t *>(mail + 2 * n + 1);
+    double *xd = mail_dev, *gd = mail_dev + n, *fdv = mail_dev + 2 * n; // the same block as the kernel sees it
+    int32_t *rqd = reinterpret_cast<int32_t *>(mail_dev + 2 * n + 1);
+    if (ok) {
+        std::copy(x, x + n, xm);
+        *fm = 0.0;
+        *rqm = 0;
+    }
     while (ok) {
-        if (fl_rci_step(h, xd, fdv, gd, rqd) != FL_OK) { ok = false; break; }
-        if (hipMemcpy(&rq, rqd, sizeof rq, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+        if (fl_rci_step(h, xd, fdv, gd, rqd) != FL_OK || hipStreamSynchronize(nullptr) != hipSuccess) { ok = false; break; }
+        const int32_t rq = *rqm;
         if (rq == 0) break;
-        if (!(rq & FL_REQ_SAME))
-            if (hipMemcpy(x, xd, sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
         if (rq & FL_REQ_H) { // info=fdd(H,x,dim): evaluate on the host, copy into the handle's padded buffer
             double *Hd = nullptr;
             int ld = 0;
             if (!ob.fdd || fl_rci_hessian_buffer(h, &Hd, &ld) != FL_OK) { ok = false; break; }
             if (hess.empty()) hess.resize((size_t)n * n);
-            ob.fdd(hess.data(), x, n);
-            const size_t stride = (h->r.solver == FL_SOLVER_BFGS) ? 3 : 1; // batch of one: problem 0
-            (void)stride;
+            ob.fdd(hess.data(), xm, n);
             if (hipMemcpy2D(Hd, sizeof(double) * ld, hess.data(), sizeof(double) * n, sizeof(double) * n, n,
                             hipMemcpyHostToDevice) != hipSuccess) { ok = false; break; }
             continue;
         }
         const bool wf = rq & FL_REQ_F, wg = rq & FL_REQ_G;
         if (wf && wg && ob.f_fd) {
-            ob.f_fd(fx, g.data(), x, n); // the integer return value is ignored like the reference does (NO.f90:437)
+            ob.f_fd(*fm, gm, xm, n); // the integer return value is ignored like the reference does (NO.f90:437)
         } else {
-            if (wf) ob.f(fx, x, n);
-            if (wg) ob.fd(g.data(), x, n);
+            if (wf) ob.f(*fm, xm, n);
+            if (wg) ob.fd(gm, xm, n);
         }
-        if (wf) ok = ok && hipMemcpy(fdv, &fx, sizeof fx, hipMemcpyHostToDevice) == hipSuccess;
-        if (wg) ok = ok && hipMemcpy(gd, g.data(), sizeof(double) * n, hipMemcpyHostToDevice) == hipSuccess;
     }
     double gg = 0.0;
     if (ok) {
-        ok = hipMemcpy(x, xd, sizeof(double) * n, hipMemcpyDeviceToHost) == hipSuccess &&
-             hipMemcpy(&status, h->r.status, sizeof status, hipMemcpyDeviceToHost) == hipSuccess &&
+        std::copy(xm, xm + n, x); // the minimiser (the kernel's finish() wrote it into the mailbox)
+        ok = hipMemcpy(&status, h->r.status, sizeof status, hipMemcpyDeviceToHost) == hipSuccess &&
              hipMemcpy(&gg, h->r.gg_out, sizeof gg, hipMemcpyDeviceToHost) == hipSuccess;
     }
     if (!ok) std::fprintf(stderr, "FortranLibrary(MI355X) %s: HIP error during the solve\n", name);
@@ -546,10 +550,7 @@ static int legacy_solve(int solver, const char *name, const HostObjective &ob, d
                         " Euclidean norm of gradient = %24.16E\n", name, sqrt(gg));
         }
     }
-    if (xd) (void)hipFree(xd);
-    if (fdv) (void)hipFree(fdv);
-    if (gd) (void)hipFree(gd);
-    if (rqd) (void)hipFree(rqd);
+    if (mail) (void)hipHostFree(mail);
     fl_rci_destroy(h);
     return ok ? status : FL_ERR_LAUNCH;
 }
@@ -567,20 +568,27 @@ static void legacy_line_search(int strong, int fused, const double *c1, const do
         return;
     }
     const double incr = Increment ? *Increment : 1.05; // fail-safe max(1+1d-15, Increment) inside the machine
-    double *x0d = nullptr, *pd = nullptr, *xd = nullptr, *gd = nullptr, *fd_dev = nullptr, *sc = nullptr;
-    int32_t *rqd = nullptr;
+    // x0, p and the parked machine on the device; the trial point, f'(x), f and the request in a pinned, device-mapped
+    // mailbox (see legacy_solve)
+    double *x0d = nullptr, *pd = nullptr, *sc = nullptr, *mail = nullptr, *mail_dev = nullptr;
     const size_t vb = sizeof(double) * (size_t)n;
     bool ok = hipMalloc((void **)&x0d, vb) == hipSuccess && hipMalloc((void **)&pd, vb) == hipSuccess &&
-              hipMalloc((void **)&xd, vb) == hipSuccess && hipMalloc((void **)&gd, vb) == hipSuccess &&
-              hipMalloc((void **)&fd_dev, sizeof(double)) == hipSuccess &&
               hipMalloc((void **)&sc, 32 * sizeof(double)) == hipSuccess &&
-              hipMalloc((void **)&rqd, sizeof(int32_t)) == hipSuccess;
+              hipHostMalloc((void **)&mail, sizeof(double) * (2 * (size_t)n + 2), hipHostMallocMapped) == hipSuccess &&
+              hipHostGetDevicePointer((void **)&mail_dev, mail, 0) == hipSuccess;
+    double *xm = mail, *gm = mail + n, *fm = mail + 2 * n;
+    volatile int32_t *rqm = reinterpret_cast<volatile int32_t *>(mail + 2 * n + 1);
+    double *xd = mail_dev, *gd = mail_dev + n, *fd_dev = mail_dev + 2 * n;
+    int32_t *rqd = reinterpret_cast<int32_t *>(mail_dev + 2 * n + 1);
     ok = ok && hipMemcpy(x0d, x, vb, hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemcpy(xd, x, vb, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(pd, p, vb, hipMemcpyHostToDevice) == hipSuccess;
-    int32_t rq = 0;
+    if (ok) {
+        std::copy(x, x + n, xm);
+        std::copy(fdx, fdx + n, gm); // (what the caller's array holds stays if no gradient is ever asked for)
+        *fm = *fx;
+        *rqm = 0;
+    }
     int first = 1;
-    double fv = *fx;
     const int nw = threads / 64, nslot = ept / 2;
     while (ok) {
 #define FL_LS(NW_)                                                                                                \
@@ -595,19 +603,20 @@ static void legacy_line_search(int strong, int fused, const double *c1, const do
         }
 #undef FL_LS
         first = 0;
-        if (hipMemcpy(&rq, rqd, sizeof rq, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+        if (hipStreamSynchronize(nullptr) != hipSuccess) { ok = false; break; }
+        const int32_t rq = *rqm;
         if (rq == 0) break;
-        if (!(rq & FL_REQ_SAME))
-            if (hipMemcpy(x, xd, vb, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
         const bool wf = rq & FL_REQ_F, wg = rq & FL_REQ_G;
         if (wf && wg && f_fd) {
-            (void)f_fd(fv, fdx, x, n);
+            (void)f_fd(*fm, gm, xm, n);
         } else {
-            if (wf) f(fv, x, n);
-            if (wg) fd(fdx, x, n);
+            if (wf) f(*fm, xm, n);
+            if (wg) fd(gm, xm, n);
         }
-        if (wf) ok = ok && hipMemcpy(fd_dev, &fv, sizeof fv, hipMemcpyHostToDevice) == hipSuccess;
-        if (wg) ok = ok && hipMemcpy(gd, fdx, vb, hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (ok) { // on exit, like the reference: x = x + a p and fdx = f'(x) there (the last evaluation)
+        std::copy(xm, xm + n, x);
+        std::copy(gm, gm + n, fdx);
     }
     if (ok) {
         double st[8];
@@ -618,9 +627,10 @@ static void legacy_line_search(int strong, int fused, const double *c1, const do
         }
     }
     if (!ok) std::fprintf(stderr, "FortranLibrary(MI355X) line search: HIP error\n");
-    void *bufs[] = {x0d, pd, xd, gd, fd_dev, sc, rqd};
+    void *bufs[] = {x0d, pd, sc};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
+    if (mail) (void)hipHostFree(mail);
 }
 
 // optional dummy arguments arrive as NULL when absent (Fortran callers); C++ always passes all
