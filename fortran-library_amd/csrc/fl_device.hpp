@@ -368,11 +368,14 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
 #define FL_REG_PAIRS_E8 1 // measured (profiles/r02/ab_pairs.txt): 0, 1, 2 register pairs: 198, 176, 179 ms per solve
 #endif
 #ifndef FL_REG_PAIRS_E4
-#define FL_REG_PAIRS_E4 0
+#define FL_REG_PAIRS_E4 2 // n = 256 (1x4): 0 / 2 / 3 / 4 pairs 91.8 / 101.3 / 86.8 / 87.0 M it/s; n = 512 (2x4): 51.0 / 56.2 / 57.6 / 56.0
+#endif
+#ifndef FL_REG_PAIRS_E8W
+#define FL_REG_PAIRS_E8W 1 // 4 x 8 and 8 x 8 (n > 1024): n = 2048: 0 / 1 / 2 pairs 110.0 / 101.1 / 103.2 ms, n = 4096: 153.1 / 142.4 / 144.4
 #endif
     static constexpr int REG_PAIRS = (METHOD == FL_SOLVER_LBFGS && OBJ != FL_OBJ_EXTERNAL && !AUG)
-                                         ? ((EPT >= 8 && NW <= 2) ? FL_REG_PAIRS_E8 : (EPT == 4 ? FL_REG_PAIRS_E4 : 0)) : 0;
-    static_assert(REG_PAIRS >= 0 && REG_PAIRS <= 2, "0, 1 or 2 register pairs");
+                                         ? (EPT >= 8 ? (NW <= 2 ? FL_REG_PAIRS_E8 : FL_REG_PAIRS_E8W) : (EPT == 4 ? FL_REG_PAIRS_E4 : 0)) : 0;
+    static_assert(REG_PAIRS >= 0 && REG_PAIRS <= 4, "0 .. 4 register pairs");
     // Newton: one row buffer for the Cholesky kernels (BFGS reuses its broadcast arrays)
     static constexpr int L_DEF = L_BF + (METHOD == FL_SOLVER_BFGS ? 3 * NPAD : (METHOD == FL_SOLVER_NEWTON ? NPAD : 0));
     // BFGS for n > 1024, fused kernels: the rank-2 updates are DEFERRED -- H is left alone for BF_DEFER iterations
@@ -1152,9 +1155,9 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
         constexpr int J0 = RP > 1 ? RP : 1, L = RP;
         if (cnt > J0) fetch(J0, sB, yB);
         down(0, sv, yv);
-        if constexpr (RP == 2) {
-            if (cnt > 1) down(1, rs_[1], ry_[1]);
-        }
+#pragma unroll
+        for (int r_ = 1; r_ < RP; ++r_)
+            if (cnt > r_) down(r_, rs_[r_], ry_[r_]);
         for (int j = J0; j < cnt; j += 2) {
             if (j + 1 < cnt) fetch(j + 1, sA, yA);
             down(j, sB, yB);
@@ -1186,9 +1189,9 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
                 upw(j - 1, sA, yA);
             }
         }
-        if constexpr (RP == 2) {
-            if (cnt > 1) upw(1, rs_[1], ry_[1]);
-        }
+#pragma unroll
+        for (int r_ = RP - 1; r_ >= 1; --r_)
+            if (cnt > r_) upw(r_, rs_[r_], ry_[r_]);
         if constexpr (RP >= 1) upw(0, rs_[0], ry_[0]);
 #pragma unroll
         for (int k = 0; k < EPT; ++k) p[k] = -p[k];
