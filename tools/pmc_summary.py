@@ -23,9 +23,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def _newest(files):
+    """gpurun merges every run's output into the same directory: of several runs' files keep the most recent"""
+    files = list(files)
+    return [max(files, key=os.path.getmtime)] if files else []
+
+
 def kernel_stats(root):
     out = {}
-    for f in glob.glob(os.path.join(root, "kt", "**", "*kernel_stats.csv"), recursive=True):
+    for f in _newest(glob.glob(os.path.join(root, "kt", "**", "*kernel_stats.csv"), recursive=True)):
         for r in csv.DictReader(open(f)):
             out[r["Name"]] = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
                               "total_ms": float(r["TotalDurationNs"]) / 1e6, "pct": float(r["Percentage"]), "file": f}
@@ -35,7 +41,12 @@ def kernel_stats(root):
 def counters(root, match):
     """{counter: (sum per dispatch of kernels whose name contains `match`, dispatches, csv path)}"""
     res, info = {}, None
-    for f in sorted(glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
+    passes = sorted(glob.glob(os.path.join(root, "pmc_*")))
+    files = []
+    for d in passes:
+        if os.path.isdir(d):
+            files += _newest(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True))
+    for f in files:
         acc, nd = collections.defaultdict(float), set()
         for r in csv.DictReader(open(f)):
             if match not in r["Kernel_Name"]:
