@@ -361,6 +361,45 @@ def minimize_rci_auglag(solver, x, fun, M, lambda0=None, miu0=1.0, options=None,
     return out
 
 
+def TrustRegion(x, fun, M, low=None, up=None, MaxIteration=1000, MaxStepIteration=100, Precision=1e-15,
+                MinStepLength=1e-15, max_steps=100000, check_every=4):
+    """TrustRegion (NO.f90:1728) for a batch on the device: `fun(x, request)` returns (r [batch, M], J [batch, N, M])
+    CUDA tensors -- residuals f'(x) and the column-major M x N Jacobians -- for the whole batch (it may skip problems
+    whose request bits do not ask).  x [batch, N] is updated in place; returns resnorm, iters, reason."""
+    import torch
+    B, N = x.shape
+    FL.fl_trust_region_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                          C.c_int, C.c_double, C.c_double, C.c_void_p]
+    FL.fl_trust_region_step.argtypes = [C.c_void_p] * 5
+    FL.fl_trust_region_results.argtypes = [C.c_void_p] * 4
+    FL.fl_trust_region_destroy.argtypes = [C.c_void_p]
+    h = C.c_void_p()
+    _check(FL.fl_trust_region_create(C.byref(h), B, M, N, _ptr(low) if low is not None else None,
+                                     _ptr(up) if up is not None else None, MaxIteration, MaxStepIteration, Precision,
+                                     MinStepLength, _stream()), "fl_trust_region_create")
+    try:
+        req = torch.empty(B, dtype=torch.int32, device=x.device)
+        _check(FL.fl_trust_region_step(h, _ptr(x), None, None, _ptr(req)), "fl_trust_region_step")
+        steps = 0
+        r = J = None
+        while steps < max_steps:
+            if steps % check_every == 0 and not bool((req != 0).any()):
+                break
+            r, J = fun(x, req)
+            r, J = r.to(torch.float64).contiguous(), J.to(torch.float64).contiguous()
+            _check(FL.fl_trust_region_step(h, _ptr(x), _ptr(r), _ptr(J), _ptr(req)), "fl_trust_region_step")
+            steps += 1
+        out = {"resnorm": torch.empty(B, dtype=torch.float64, device=x.device),
+               "iters": torch.empty(B, dtype=torch.int32, device=x.device),
+               "reason": torch.empty(B, dtype=torch.int32, device=x.device), "steps": steps}
+        _check(FL.fl_trust_region_results(h, _ptr(out["resnorm"]), _ptr(out["iters"]), _ptr(out["reason"])),
+               "fl_trust_region_results")
+        torch.cuda.synchronize()
+    finally:
+        FL.fl_trust_region_destroy(h)
+    return out
+
+
 def dgemm(A, B, transA=False):
     """My_dgemm / My_dgemm_T on device tensors.  Column-major operands given as torch tensors of the TRANSPOSED shape
     (a row of the tensor = a column of the matrix): A [K, M] holds the M x K matrix (transA: A [M, K] holds the K x M

@@ -277,6 +277,28 @@ int fl_rci_step_auglag(fl_rci *handle, double *x_dev, const double *f_dev, const
                        const double *cd_dev, int32_t *request_dev);
 int fl_rci_results_auglag(fl_rci *handle, double *cnorm2_dev, int32_t *outer_dev);
 
+/* ---- TrustRegion (NO.f90:1728-1906) for a batch, on the device, by reverse communication ------------------------
+ * Solves f'(x) = 0 in the least-squares sense (M equations, N unknowns, M >= N; optional box low <= x <= up shared by
+ * the batch) for `batch` independent problems.  The reference wraps MKL's closed dtrnlsp solver; this is the library's
+ * own Levenberg-Marquardt iteration (parity unpinned by construction) behind the reference's stopping options
+ * (MaxIteration, MaxStepIteration, Precision on ||f'(x)||_2, MinStepLength on the step).  Ask / tell:
+ *   fl_trust_region_step(h, x_dev, r_dev, J_dev, request_dev): first call x_dev [batch][N] = starting points (r_dev,
+ *   J_dev may be NULL); afterwards r_dev [batch][M] = f'(x) and J_dev [batch][N][M] = the M x N Jacobian, column-major
+ *   (the Fortran array Jacobian(M,N)), evaluated at x_dev[k] where request_dev[k] asked for them: bit FL_TRS_REQ_R (1)
+ *   residual, FL_TRS_REQ_J (2) Jacobian (arrays of problems not asked are left as they were), FL_TRS_REQ_AGAIN (4)
+ *   nothing to evaluate for this problem but it has not finished, 0 finished (x_dev[k] = the solution).
+ * fl_trust_region_results: ||f'(x)||_2, accepted iterations, stopping reason (1 MaxIteration, 2 MaxStepIteration,
+ * 3 Precision met, 4 stationary point of |f'|^2, 5 MinStepLength). */
+#define FL_TRS_REQ_R 1
+#define FL_TRS_REQ_J 2
+#define FL_TRS_REQ_AGAIN 4
+typedef struct fl_trs fl_trs;
+int fl_trust_region_create(fl_trs **handle, int batch, int M, int N, const double *low_dev, const double *up_dev,
+                           int max_iteration, int max_step_iteration, double precision, double min_step_length, void *stream);
+int fl_trust_region_step(fl_trs *handle, double *x_dev, const double *r_dev, const double *J_dev, int32_t *request_dev);
+int fl_trust_region_results(fl_trs *handle, double *resnorm_dev, int32_t *iters_dev, int32_t *reason_dev);
+int fl_trust_region_destroy(fl_trs *handle);
+
 /* The L-BFGS two-loop recursion alone (Before(), NO.f90:586-608) for a batch:
  * p = -H_k g from a full ring of `memory` pairs.  hist_dev is the solver's
  * history layout [batch][2*memory][npad] (npad = threads*ept; pair i: s at
