@@ -229,11 +229,11 @@ def BFGS(objective, x, d=None, b=None, workspace_=None, options=None, **kw):
 def AugmentedLagrangian(objective, x, M, d=None, b=None, UnconstrainedSolver="LBFGS", lambda0=None, miu0=1.0,
                         workspace_=None, options=None, **kw):
     """Batched augmented Lagrangian with M block-sphere equality constraints (reference: subroutine
-    AugmentedLagrangian, NO.f90:2005-2241).  UnconstrainedSolver: 'LBFGS' | 'ConjugateGradient' | 'BFGS' (pass
-    ExactStep=0: the quasi-Newton branch).  lambda0: optional [batch, M] tensor, updated in place (returned as
+    AugmentedLagrangian, NO.f90:2005-2241).  UnconstrainedSolver: 'LBFGS' | 'ConjugateGradient' | 'BFGS' | 'NewtonRaphson'
+    (the last two with the analytic Hessian of L, n <= 2048; BFGS with ExactStep=0: quasi-Newton only).  lambda0: optional [batch, M] tensor, updated in place (returned as
     out['lambda'])."""
     import torch
-    solvers = {"LBFGS": LBFGS_, "ConjugateGradient": CG, "BFGS": BFGS_}
+    solvers = {"LBFGS": LBFGS_, "ConjugateGradient": CG, "BFGS": BFGS_, "NewtonRaphson": 4}
     if UnconstrainedSolver not in solvers:  # reference: "Program abort: unsupported unconstrained solver" (NO.f90:2186)
         raise ValueError("unsupported unconstrained solver on the device path: " + str(UnconstrainedSolver))
     solver = solvers[UnconstrainedSolver]
@@ -244,8 +244,8 @@ def AugmentedLagrangian(objective, x, M, d=None, b=None, UnconstrainedSolver="LB
     if ws is None:
         if solver == LBFGS_:
             ws = workspace(B, n, o.memory, x.device)
-        elif solver == BFGS_:
-            ws = bfgs_workspace(B, n, x.device, o)
+        elif solver == BFGS_ or solver == 4:
+            ws = bfgs_workspace(B, n, x.device, o, solver=solver)
         else:
             ws = torch.empty(1, dtype=torch.float64, device=x.device)
     out["outer"] = torch.empty(B, dtype=torch.int32, device=x.device)

@@ -521,7 +521,8 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
                 }
             }
             miu = A.miu0 > 1.0 ? A.miu0 : 1.0; // miu=max(1d0,miu0)
-            if ((int)threadIdx.x < A.aug_m) lds[L_LAM + threadIdx.x] = A.lambda[(size_t)prob * A.aug_m + threadIdx.x];
+            const int tl = G::tid();
+            if (tl < A.aug_m) lds[L_LAM + tl] = A.lambda[(size_t)prob * A.aug_m + tl];
             __syncthreads();
         }
     }
@@ -614,7 +615,8 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
 #pragma unroll
             for (int k = 0; k < EPT; ++k) {
                 if (blk[k] >= 0) {
-                    const int j = blk[k];
+                    int j = blk[k];
+                    asm volatile("" : "+v"(j)); // (the LDS addresses of c_j, lambda_j are formed here, not kept from init())
                     const double v = miu * cxs[j] - lds[L_LAM + j];
                     g[k] = g[k] + (2.0 * x[k]) * v; // Ldx=Ldx+matmul(cdx,miu*cx-lambda)
                 }
@@ -656,7 +658,8 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
         const int m = A.aug_m;
         double *cxs = lds + L_CX;
         __syncthreads(); // readers of the previous c(x) are done
-        if ((int)threadIdx.x < m) cxs[threadIdx.x] = c_user[threadIdx.x];
+        const int tl = G::tid();
+        if (tl < m) cxs[tl] = c_user[tl];
         __syncthreads();
         if (have_f) {
             double lc = 0.0, c2 = 0.0;
@@ -817,6 +820,42 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
     __device__ __forceinline__ void fill_hessian(double *Hm)
     {
         if constexpr (HESS_RCI) return; // reverse communication: the caller has written it (FL_REQ_H)
+        if constexpr (AUG) {
+            // Hessian of the augmented Lagrangian as the reference's Ldd forms it (NO.f90:2229-2241):
+            //   Lddx = (fdd + [matmul(cddx(i,:,:), miu*cx - lambda)]_i) + matmul(cdx, transpose(cdx))
+            // -- note: no miu on the last term, as written.  Block spheres: c_j'' = 2 I on block j, grad c_j = 2 x on
+            // block j, so column j gets 2 v_b on the diagonal and (2 x_i)(2 x_j) on the rows of its block b.
+            // c(x) of the last evaluation (= the current x) is in LDS; x is staged in the first row buffer.
+            double *xstage = lds + L_BF;
+            const double *cxs = lds + L_CX;
+            __syncthreads();
+            store_pad<NW, EPT>(xstage, x);
+            __syncthreads();
+            const int w = n / A.aug_m;
+            // two sweeps over the columns (every thread re-reads only what it wrote): the objective's part first, then
+            // the constraint terms -- together they were 31 VGPRs too many for the 512-thread kernel
+            for (int j = 0; j < n; ++j) {
+                double h[EPT];
+                obj.hess_column(j, x, n, lds + L_XS, h);
+                store_pad<NW, EPT>(Hm + (size_t)j * NPAD, h);
+            }
+            for (int j = 0; j < n; ++j) {
+                double h[EPT];
+                load_pad<NW, EPT>(Hm + (size_t)j * NPAD, h);
+                const int bj = j / w;
+                const double vb = miu * cxs[bj] - lds[L_LAM + bj], xj2 = 2.0 * xstage[j];
+#pragma unroll
+                for (int k = 0; k < EPT; ++k) {
+                    const int i = G::e0(k >> 1) + (k & 1);
+                    const double t = (i == j) ? 2.0 * vb : 0.0;
+                    const double pterm = (blk[k] == bj) ? (2.0 * x[k]) * xj2 : 0.0;
+                    h[k] = (h[k] + t) + pterm;
+                }
+                store_pad<NW, EPT>(Hm + (size_t)j * NPAD, h);
+            }
+            __syncthreads();
+            return;
+        }
         for (int j = 0; j < n; ++j) {
             double h[EPT];
             obj.hess_column(j, x, n, lds + L_XS, h);
@@ -989,15 +1028,17 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
             ++outer_it;
             inner_iters_total += iters;
             iters = 0;
-            const double tolsq = A.precision * A.precision;
+            const double tolsq = uni(A.precision * A.precision); // (pinned to SGPRs: a loop invariant the compiler
+                                                                 //  would otherwise carry in a VGPR pair for the whole solve)
             if (c2 < tolsq) { // if(dot_product(cx,cx)<tolsq) exit
                 status = FL_STATUS_CONVERGED;
                 phase = PH_DONE;
                 return 0;
             }
             __syncthreads();
-            if ((int)threadIdx.x < m) // lambda=lambda-miu*cx
-                lds[L_LAM + threadIdx.x] = lds[L_LAM + threadIdx.x] - miu * cxs[threadIdx.x];
+            const int tl = G::tid();
+            if (tl < m) // lambda=lambda-miu*cx
+                lds[L_LAM + tl] = lds[L_LAM + tl] - miu * cxs[tl];
             __syncthreads();
             miu = uni(miu * A.incr); // miu=miu*incrmt
             if (outer_it >= A.maxit) { // do iIteration=1,maxit exhausted
@@ -1535,7 +1576,8 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
         }
         if constexpr (AUG) { // lambda lives in LDS during a launch and in the caller's array between launches
             __syncthreads();
-            if ((int)threadIdx.x < A.aug_m) A.lambda[(size_t)prob * A.aug_m + threadIdx.x] = lds[L_LAM + threadIdx.x];
+            const int tl = G::tid();
+            if (tl < A.aug_m) A.lambda[(size_t)prob * A.aug_m + tl] = lds[L_LAM + tl];
         }
     }
     __device__ __forceinline__ void load(const double *sc, const double *vec, const double *rho, double &fv_c,
@@ -1594,8 +1636,8 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
         store_user<NW, EPT>(A.x + (size_t)prob * n, n, x);
         if constexpr (AUG) {
             __syncthreads();
-            if ((int)threadIdx.x < A.aug_m)
-                A.lambda[(size_t)prob * A.aug_m + threadIdx.x] = lds[L_LAM + threadIdx.x];
+            const int tl = G::tid();
+            if (tl < A.aug_m) A.lambda[(size_t)prob * A.aug_m + tl] = lds[L_LAM + tl];
         }
         if (threadIdx.x == 0) {
             if (A.f_out) A.f_out[prob] = fnew;

@@ -136,6 +136,12 @@ template <int NW, int EPT, int OBJ> static hipError_t launch_m(int method, int a
 {
     if (aug) { // augmented Lagrangian around L-BFGS, CG (NO.f90:2150-2185) or quasi-Newton BFGS (2131-2148, ExactStep <= 0)
         if (method == FL_SOLVER_CG) return launch_k<NW, EPT, OBJ, FL_SOLVER_CG, 1>(A, st);
+        // NewtonRaphson / exact-Hessian BFGS around the Hessian of L (Ldd): up to n = 2048 (solve() refuses beyond: at 512
+        // threads the Cholesky kernels, the deferred updates and the constraint terms together do not fit 256 VGPRs)
+        if constexpr (NW < 8) {
+            if (method == FL_SOLVER_NEWTON) return launch_k<NW, EPT, OBJ, FL_SOLVER_NEWTON, 1>(A, st); // fdd=Ldd (2074-2130)
+            if (method == FL_SOLVER_BFGS && A.exact_step > 0) return launch_k<NW, EPT, OBJ, FL_SOLVER_BFGS, 1, 1>(A, st);
+        }
         if (method == FL_SOLVER_BFGS) return launch_k<NW, EPT, OBJ, FL_SOLVER_BFGS, 1, 0>(A, st);
         return launch_k<NW, EPT, OBJ, FL_SOLVER_LBFGS, 1>(A, st);
     }
@@ -246,10 +252,12 @@ static int solve(int method, int objective, int batch, int n, double *x, const d
     if (aug) {
         if (aug->m < 1 || aug->m > FL_MAX_CONSTRAINTS || n % aug->m != 0 || !aug->lambda)
             return FL_ERR_INVALID_ARGUMENT;
-        if (method != FL_SOLVER_LBFGS && method != FL_SOLVER_CG && method != FL_SOLVER_BFGS) return FL_ERR_INVALID_ARGUMENT;
-        // inner BFGS: the quasi-Newton branch only (the reference's default ExactStep = 20 would take numerical
-        // Hessians of L from MKL's djacobi when no fdd / cdd is passed, NO.f90:2131-2148)
-        if (method == FL_SOLVER_BFGS && opt->exact_step > 0) return FL_ERR_INVALID_ARGUMENT;
+        // the reference's whole menu (NO.f90:2074-2185): NewtonRaphson and BFGS take the analytic Hessian of L (the fdd /
+        // cdd branch, Ldd) -- the built-in objectives and constraints have one; BFGS with exact_step <= 0 never asks
+        if (method != FL_SOLVER_LBFGS && method != FL_SOLVER_CG && method != FL_SOLVER_BFGS && method != FL_SOLVER_NEWTON)
+            return FL_ERR_INVALID_ARGUMENT;
+        if ((method == FL_SOLVER_NEWTON || (method == FL_SOLVER_BFGS && opt->exact_step > 0)) && n > 2048)
+            return FL_ERR_UNSUPPORTED_SIZE;
         A.aug_m = aug->m;
         A.miu0 = aug->miu0;
         A.lambda = aug->lambda;

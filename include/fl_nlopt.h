@@ -209,8 +209,10 @@ int fl_bfgs_update_gemm_batched(int batch, int n, double *H_dev, const double *s
 
 /* Augmented Lagrangian for equality constraints (subroutine AugmentedLagrangian, NO.f90:2005-2241;
  * C++ binding cpp/NonlinearOptimization.hpp:367-392) around solver = FL_SOLVER_LBFGS (NO.f90:2150-2167),
- * FL_SOLVER_CG (NO.f90:2168-2185) or FL_SOLVER_BFGS with opt->exact_step <= 0 (NO.f90:2131-2148 with ExactStep = 0:
- * quasi-Newton updates only; workspace as for fl_bfgs_batched).  Built-in constraint family: m block spheres
+ * FL_SOLVER_CG (NO.f90:2168-2185), FL_SOLVER_BFGS (NO.f90:2131-2148: quasi-Newton with opt->exact_step <= 0, or with the
+ * exact inverse Hessian of L every exact_step iterations) or FL_SOLVER_NEWTON (NO.f90:2074-2130); the last two take the
+ * analytic Hessian of the augmented Lagrangian as the reference's Ldd forms it (NO.f90:2229-2241; n <= 2048).
+ * Workspace as for the inner solver alone (fl_workspace_bytes_for).  Built-in constraint family: m block spheres
  * c_j(x) = sum_{i in block j} x_i^2 - 1 over m consecutive blocks of n/m elements (m = 1 is the unit
  * sphere of the reference's test, test/test.f90:699-721); m <= 16, n % m == 0.
  * lambda_dev [batch][m] in/out (lambda0 -> final multipliers), miu0 as the reference (clamped to >= 1).

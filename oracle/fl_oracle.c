@@ -1190,9 +1190,11 @@ typedef struct {
     flo_ffd_t f_fd;
     flo_c_t c;
     flo_cd_t cd;
+    flo_fdd_t fdd; /* with cdd: the Hessian of L is available (Ldd, NO.f90:2229) */
+    int (*cdd)(double *, const double *, int, int, void *);
     void *ctx;
     int m;
-    double *lambda, miu, *cx, *cdx, *v;
+    double *lambda, miu, *cx, *cdx, *v, *cddx, *tmp;
     int nf, ng, nc;
 } al_t;
 
@@ -1254,6 +1256,29 @@ static int al_L_Ld(double *Lx, double *Ldx, const double *x, int n, void *vp) /*
     return 0;
 }
 
+/* Ldd, NO.f90:2229-2241:  i=fdd(Lddx,x,N); i=cdd(cddx,x,M,N); call c(cx,...); call cd(cdx,...); cx=miu*cx-lambda;
+ * Lddxtemp(:,i)=matmul(cddx(i,:,:),cx); Lddx=Lddx+Lddxtemp+matmul(cdx,transpose(cdx))   (no miu on the last term: as
+ * written).  H column-major n x n; cddx(N,N,M): element (i,k,j) at i + k*n + j*n*n; cdx(N,M): (k,j) at k + j*n. */
+static int al_Ldd(double *H, const double *x, int n, void *vp)
+{
+    al_t *A = (al_t *)vp;
+    const int m = A->m;
+    A->fdd(H, x, n, A->ctx);
+    A->cdd(A->cddx, x, m, n, A->ctx);
+    A->c(A->cx, x, m, n, A->ctx);
+    A->nc++;
+    A->cd(A->cdx, x, m, n, A->ctx);
+    for (int j = 0; j < m; ++j) A->v[j] = A->miu * A->cx[j] - A->lambda[j];
+    for (int i = 0; i < n; ++i)     /* column i */
+        for (int k = 0; k < n; ++k) { /* row k */
+            double t = 0.0, p = 0.0;
+            for (int j = 0; j < m; ++j) t = t + A->cddx[(size_t)i + (size_t)k * n + (size_t)j * n * n] * A->v[j];
+            for (int j = 0; j < m; ++j) p = p + A->cdx[(size_t)k + (size_t)j * n] * A->cdx[(size_t)i + (size_t)j * n];
+            H[(size_t)k + (size_t)i * n] = (H[(size_t)k + (size_t)i * n] + t) + p;
+        }
+    return 0;
+}
+
 /* AugmentedLagrangian, NO.f90:2005-2241 (LBFGS case 2150-2167, CG 2168-2185,
  * BFGS without fdd/cdd 2131-2148).  st->nf/ng count USER f/fd calls. */
 /* update form of the inner BFGS (0 = as written; 1 / 100+J = what the kernels evaluate): set once before a run */
@@ -1264,7 +1289,22 @@ void flo_augmented_lagrangian(flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, flo_c_t c,
                               int m, int solver, double *lambda, double miu0, const flo_opts *o, void *ctx,
                               flo_stats *st, int *outer_iters, double *cnorm2)
 {
+    flo_augmented_lagrangian_h(f, fd, f_fd, NULL, c, cd, NULL, x, n, m, solver, lambda, miu0, o, ctx, st, outer_iters, cnorm2);
+}
+
+/* the same with fdd and cdd (both or neither): solver 3 = NewtonRaphson (NO.f90:2074-2130), solver 0 = BFGS takes the
+ * exact inverse Hessian of L every o->exact_step iterations when they are present (2131-2148) */
+void flo_augmented_lagrangian_h(flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, flo_fdd_t fdd, flo_c_t c, flo_cd_t cd,
+                                int (*cdd)(double *, const double *, int, int, void *), double *x, int n, int m, int solver,
+                                double *lambda, double miu0, const flo_opts *o, void *ctx, flo_stats *st,
+                                int *outer_iters, double *cnorm2)
+{
     al_t A;
+    const int hess = fdd && cdd;
+    A.fdd = fdd;
+    A.cdd = cdd;
+    A.cddx = hess ? (double *)malloc(sizeof(double) * (size_t)n * n * m) : NULL;
+    A.tmp = NULL;
     flo_stats in;
     double tolsq = o->precision * o->precision, cc = 0.0;
     A.f = f;
@@ -1288,8 +1328,10 @@ void flo_augmented_lagrangian(flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, flo_c_t c,
             flo_lbfgs(al_L, al_Ld, al_L_Ld, x, n, o, &A, &in);
         else if (solver == 2)
             flo_conjugate_gradient(al_L, al_Ld, al_L_Ld, x, n, o, &A, &in);
+        else if (solver == 3)
+            flo_newton(al_L, al_Ld, al_L_Ld, hess ? al_Ldd : NULL, x, n, o, &A, &in);
         else
-            flo_bfgs(al_L, al_Ld, al_L_Ld, NULL, x, n, o, al_bfgs_form, &A, &in);
+            flo_bfgs(al_L, al_Ld, al_L_Ld, hess ? al_Ldd : NULL, x, n, o, al_bfgs_form, &A, &in);
         st->iters += in.iters;
         st->f = in.f;
         st->gg = in.gg;
@@ -1308,4 +1350,5 @@ void flo_augmented_lagrangian(flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, flo_c_t c,
     if (outer_iters) *outer_iters = it > o->maxit ? o->maxit : it;
     if (cnorm2) *cnorm2 = cc;
     free(A.cx);
+    free(A.cddx);
 }

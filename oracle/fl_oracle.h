@@ -104,6 +104,10 @@ int flo_lagrangian_multiplier(flo_fd_t fd, flo_fdd_t fdd, flo_c_t c, flo_cd_t cd
 /* AugmentedLagrangian (NO.f90:2005): solver 0 = BFGS, 1 = LBFGS, 2 = ConjugateGradient.
  * lambda[m] in/out (reference: lambda0 copy), miu0 as given. outer_iters returns the
  * number of outer iterations. */
+void flo_augmented_lagrangian_h(flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, flo_fdd_t fdd, flo_c_t c, flo_cd_t cd,
+                                int (*cdd)(double *, const double *, int, int, void *), double *x, int n, int m, int solver,
+                                double *lambda, double miu0, const flo_opts *o, void *ctx, flo_stats *st,
+                                int *outer_iters, double *cnorm2); /* with fdd, cdd: Ldd (solver 3 = NewtonRaphson) */
 void flo_set_auglag_bfgs_form(int form); /* BFGS update form inside flo_augmented_lagrangian (default 0 = as written) */
 void flo_augmented_lagrangian(flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, flo_c_t c, flo_cd_t cd, double *x, int n,
                               int m, int solver, double *lambda, double miu0, const flo_opts *o, void *ctx,

@@ -607,3 +607,50 @@ def test_augmented_lagrangian_with_bfgs_inner_solver_bitexact(kind, n, m, kw):
     assert np.array_equal(g["x"].view(np.uint64), o["x"].view(np.uint64))
     assert np.array_equal(g["lambda"].view(np.uint64), o["lam"].view(np.uint64))
     assert np.array_equal(g["cnorm2"].view(np.uint64), o["cnorm2"].view(np.uint64))
+
+
+@pytest.mark.parametrize("solver_name,solver,kind,n,m,kw", [
+    ("NewtonRaphson", 4, O.QUARTIC, 10, 1, {"Precision": 1e-8}),   # test/test.f90:452-478 with UnconstrainedSolver='NewtonRaphson'
+    ("NewtonRaphson", 4, O.DIAGQUAD, 64, 8, {"Precision": 1e-8}),
+    ("NewtonRaphson", 4, O.ROSENBROCK, 96, 3, {"Precision": 1e-7}),
+    ("BFGS", O.BFGS, O.QUARTIC, 10, 1, {"Precision": 1e-8, "ExactStep": 5}),
+    ("BFGS", O.BFGS, O.DIAGQUAD, 64, 8, {"Precision": 1e-8, "ExactStep": 20}),   # the reference's default cadence
+    ("BFGS", O.BFGS, O.ROSENBROCK, 96, 3, {"Precision": 1e-7, "ExactStep": 3}),
+])
+def test_augmented_lagrangian_with_the_hessian_of_L_bitexact(solver_name, solver, kind, n, m, kw):
+    """UnconstrainedSolver = 'NewtonRaphson' / 'BFGS' with fdd and cdd present (NO.f90:2074-2148): the inner solver
+    takes the Hessian of the augmented Lagrangian as the reference's Ldd forms it (NO.f90:2229-2241 -- including its
+    missing miu on cd cd^T).  Oracle: flo_augmented_lagrangian_h with the problems' analytic fdd / cdd."""
+    NLO = _nlo()
+    rng = np.random.default_rng(13 * n + m)
+    B = 3
+    i = np.arange(1, n + 1).astype(float)
+    x0 = 0.1 + 0.05 * np.cos(i)[None, :] + 0.01 * rng.standard_normal((B, n))
+    if kind == O.QUARTIC:
+        x0 = rng.random((B, n))
+    d = b = None
+    if kind == O.DIAGQUAD:
+        d, b = _quads(B, n, 2.0, 10.0, 5)
+    g = _gpu_auglag(solver_name, kind, x0, m, d, b, **kw)
+    T, E = NLO.reduction_geometry(n)
+    oo = _oracle_opts(O.BFGS if solver == O.BFGS else O.LBFGS, kw)
+    oo.exact_step = int(kw.get("ExactStep", 0))
+    O.lib().flo_set_auglag_bfgs_form(1)
+    try:
+        o = O.auglag_batch(solver, kind, x0, m, d=d, b=b, opts=oo, sum_mode=O.TREE, threads=T, ept=E)
+    finally:
+        O.lib().flo_set_auglag_bfgs_form(0)
+    assert np.array_equal(g["outer"], o["outer"]), (g["outer"], o["outer"])
+    assert np.array_equal(g["iters"], o["iters"]), (g["iters"], o["iters"])
+    assert np.array_equal(g["nf"], o["nf"]) and np.array_equal(g["ng"], o["ng"])
+    assert np.array_equal(g["x"].view(np.uint64), o["x"].view(np.uint64))
+    assert np.array_equal(g["lambda"].view(np.uint64), o["lam"].view(np.uint64))
+    assert np.array_equal(g["cnorm2"].view(np.uint64), o["cnorm2"].view(np.uint64))
+
+
+def test_augmented_lagrangian_exact_inner_solvers_refuse_n_beyond_2048():
+    NLO = _nlo()
+    dev = torch.device("cuda:0")
+    x = torch.zeros(1, 2560, dtype=torch.float64, device=dev)
+    with pytest.raises(Exception):
+        NLO.AugmentedLagrangian(O.QUARTIC, x, 4, UnconstrainedSolver="NewtonRaphson")
