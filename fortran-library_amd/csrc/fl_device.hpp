@@ -332,7 +332,11 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
     static constexpr int L_ALPHA = L_RHO + FL_MAX_MEMORY;
     static constexpr int L_LAM = L_ALPHA + FL_MAX_MEMORY;        // lambda[FL_MAX_CONSTRAINTS]
     static constexpr int L_CX = L_LAM + FL_MAX_CONSTRAINTS;      // c(x)[FL_MAX_CONSTRAINTS]
-    static constexpr int L_XS = (L_CX + FL_MAX_CONSTRAINTS + 1) & ~1;
+    // scratch of the Cholesky kernels (pivot and multipliers of a block: 2 + BW doubles).  Its own slot: with the
+    // augmented Lagrangian around NewtonRaphson / exact BFGS, c(x) must survive the factorisation (inner_finished reads
+    // it when the inner solver stops on MaxIteration right after a direction)
+    static constexpr int L_SLOT = L_CX + FL_MAX_CONSTRAINTS;
+    static constexpr int L_XS = (L_SLOT + 16 + 1) & ~1;
     static constexpr int L_G0 = (L_XS + (Obj::LDS_DOUBLES > 0 ? Obj::LDS_DOUBLES : 0) + 1) & ~1;
     // BFGS: s, q, g broadcast arrays; the first one doubles as the g_old parking slot (the
     // broadcast arrays are only live inside direction_bfgs, g_old only outside it)
@@ -902,11 +906,11 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
         double *Hm = hist_base();
         fill_hessian(Hm);
         park();
-        const int info = DN::cholesky(Hm, n, lds + L_BF, lds + L_CX);
+        const int info = DN::cholesky(Hm, n, lds + L_BF, lds + L_SLOT);
 #pragma unroll
         for (int k = 0; k < EPT; ++k) p[k] = -g[k];
         if (info == 0) {
-            DN::solve(Hm, n, p, R, lds + L_CX);
+            DN::solve(Hm, n, p, R, lds + L_SLOT);
             unpark();
             direction_scalars();
             return true;
@@ -930,7 +934,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
             store_pad<NW, EPT>(gbuf, g);
             store_pad<NW, EPT>(W, x0); // wanted again only if the factorisation fails -- and then W is still untouched
         }
-        const int info = DN::cholesky(U, n, lds + L_BF, lds + L_CX);
+        const int info = DN::cholesky(U, n, lds + L_BF, lds + L_SLOT);
         if (info == 0) {
             DN::inverse_factor(U, W, n, lds + L_BF);
             DN::wtw(W, Hm, n, lds + L_BF);
