@@ -122,7 +122,10 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # FL_BENCH_FORCE_DIST=1: take the N > 1 code path (process group, gatherer, collectives of the report) with a
+    # world of one -- the only way to run that path through RCCL on a one-GPU box (tests/test_gpu_bench.py)
+    multi = world > 1 or bool(os.environ.get("FL_BENCH_FORCE_DIST"))
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -173,7 +176,7 @@ def main():
     ws = NLO.workspace(B, n, m, dev)
     opts = NLO.default_options(NLO.LBFGS_, **opt_kw)
     gat = None
-    if world > 1:  # the exchange's buffers exist before the timed region
+    if multi:  # the exchange's buffers exist before the timed region
         gat = D.Gatherer(Bglobal, {"x": ((n,), torch.float64), "f": ((), torch.float64), "iters": ((), torch.int32),
                                    "status": ((), torch.int32)}, dev, dst=0,
                          interleaved=(args.scaling == "strong" and args.interleaved))
@@ -194,7 +197,7 @@ def main():
         return out
 
     def sync():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -212,7 +215,7 @@ def main():
     my_ms = torch.tensor([sum(a.elapsed_time(bb) for a, bb in ev) / max(1, len(ev))], dtype=torch.float64, device=cdev)
     rank_iters, rank_ms = [my_iters], [my_ms]
     gather_ms = None
-    if world > 1:
+    if multi:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         rank_iters = [torch.zeros_like(my_iters) for _ in range(world)]
         rank_ms = [torch.zeros_like(my_ms) for _ in range(world)]
@@ -230,7 +233,7 @@ def main():
     total_iters_per_step = sum(per_rank_iters)
 
     if rank != 0:
-        if world > 1:
+        if multi:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -300,10 +303,10 @@ def main():
                                   if objective == NLO.DIAGQUAD else "chained Rosenbrock x0=1+0.1u, Precision 1e-10"),
                    "batch_per_gpu": B, "global_batch": Bglobal, "n": n, "memory": m, "solver": "LBFGS",
                    "line_search": "StrongWolfe",
-                   "exchange": "gather x*,f*,iters,status to rank 0" if world > 1 else "none"},
+                   "exchange": "gather x*,f*,iters,status to rank 0" if multi else "none"},
         "params_per_sec": total_iters_per_step * args.steps / dt * n,
         "iterations_per_step": total_iters_per_step,
-        "ranks": {"backend": args.backend if world > 1 else "none", "world_size": world,
+        "ranks": {"backend": args.backend if multi else "none", "world_size": world,
                   "iterations_per_rank": per_rank_iters, "kernel_ms_per_rank": per_rank_kernel_ms,
                   "gather_ms": gather_ms},
         "converged_fraction": float((status == 0).mean()),
@@ -447,7 +450,7 @@ def main():
 
     print(json.dumps(res))
     sys.stdout.flush()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     if "parity" in res and not res["parity"]["ok"]:

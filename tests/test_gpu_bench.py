@@ -44,3 +44,15 @@ def test_bench_line_one_gpu_and_two_ranks_on_one_gpu():
 def test_bench_refuses_n_gpus_without_a_launcher():
     p = subprocess.run([sys.executable, "bench.py", "--gpus", "2"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode != 0 and b"WORLD_SIZE" in p.stderr
+
+
+def test_bench_through_rccl_with_a_world_of_one():
+    """The N > 1 code path of bench.py -- process group on RCCL ("nccl"), device-resident gather buffers, the gather
+    inside the timed step, the all_reduce / all_gather of the report -- executed on the one GPU of the box with a
+    world of one (FL_BENCH_FORCE_DIST=1 under torch.distributed.run): everything but a second peer."""
+    line = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                 "127.0.0.1", "--master-port", "29613", "bench.py", "--gpus", "1", "--backend", "nccl", "--cpu-sample",
+                 "0"] + COMMON, env={"FL_BENCH_FORCE_DIST": "1"})
+    assert line["ranks"]["backend"] == "nccl" and line["ranks"]["world_size"] == 1
+    assert line["ranks"]["gather_ms"] is not None and line["config"]["exchange"].startswith("gather")
+    assert line["converged_fraction"] == 1.0 and line["iterations_per_step"] == sum(line["ranks"]["iterations_per_rank"])
