@@ -193,10 +193,13 @@ def main():
         if record:
             ev.append((e0, e1))
         if gat is not None:  # the single exchange of the path: converged results to rank 0 over xGMI
-            gat.gather({"x": x, "f": out["f"], "iters": out["iters"], "status": out["status"]}, assemble=False)
+            # (enqueued on RCCL's stream: it overlaps the next step's solve; sync() waits for the last one)
+            gat.gather({"x": x, "f": out["f"], "iters": out["iters"], "status": out["status"]}, overlap=True)
         return out
 
     def sync():
+        if gat is not None:
+            gat.finish()
         if multi:
             dist.barrier()
         torch.cuda.synchronize()
@@ -308,7 +311,7 @@ def main():
         "iterations_per_step": total_iters_per_step,
         "ranks": {"backend": args.backend if multi else "none", "world_size": world,
                   "iterations_per_rank": per_rank_iters, "kernel_ms_per_rank": per_rank_kernel_ms,
-                  "gather_ms": gather_ms},
+                  "gather_ms": gather_ms, "exchange_overlaps_next_solve": bool(multi)},
         "converged_fraction": float((status == 0).mean()),
         "roofline": {"bound": "hbm", "kernel": "fl_solve_kernel<NW,EPT,OBJ,LBFGS> (fused solver)",
                      "achieved": achieved, "achieved_source": "pmc traffic" if traffic is not None else "minimum-traffic model",

@@ -48,26 +48,45 @@ class Gatherer:
         self.stage = dist.get_backend(group) == "gloo"
         self.device = device
         buf_dev = torch.device("cpu") if self.stage else device
-        self.send, self.recv = {}, {}
+        self.send, self.recv, self.pending = {}, {}, []
         for name, (shape, dtype) in shapes.items():
             self.send[name] = torch.zeros((self.per,) + tuple(shape), dtype=dtype, device=buf_dev)
             if self.rank == dst:
                 self.recv[name] = torch.empty((self.world, self.per) + tuple(shape), dtype=dtype, device=buf_dev)
 
-    def gather(self, results, assemble=True):
+    def gather(self, results, assemble=True, overlap=False):
         """results: {name: tensor [shard, ...]} of this rank.  Returns {name: [batch, ...]} in global problem order on
         dst (views of the receive buffers where the layout allows: copy what must outlive the next call), None
         elsewhere.  assemble=False: only move the data (rank dst then holds it as self.recv[name][rank, row]); the
         interleaved order needs one reordering copy to become a flat [batch, ...] array, which a caller that only
-        wants the exchange done -- bench.py's timed step -- can skip."""
+        wants the exchange done -- bench.py's timed step -- can skip.
+
+        overlap=True (implies assemble=False): the collectives are only ENQUEUED (async_op) -- RCCL runs them on its own
+        stream, so the next batch's solve overlaps this batch's exchange.  The results were first copied into the send
+        buffers, so the caller may overwrite them at once; the buffers themselves are reused only after the previous
+        exchange has finished (the wait below), and `finish()` waits for the one in flight."""
+        self.finish()  # the send / receive buffers are free again
         for name in sorted(self.send):
             t = results[name]
             assert t.shape[0] == self.mine, (name, t.shape, self.mine)
             self.send[name][: self.mine].copy_(t)  # device -> (staged) send buffer; the pad rows stay zero
-            dist.gather(self.send[name], list(self.recv[name].unbind(0)) if self.rank == self.dst else None,
-                        dst=self.dst, group=self.group)
-        if self.rank != self.dst or not assemble:
+            w = dist.gather(self.send[name], list(self.recv[name].unbind(0)) if self.rank == self.dst else None,
+                            dst=self.dst, group=self.group, async_op=overlap)
+            if overlap:
+                self.pending.append(w)
+        if overlap or self.rank != self.dst or not assemble:
             return None
+        return self.assembled()
+
+    def finish(self):
+        """wait for the exchange enqueued by gather(..., overlap=True): the current stream (and, for gloo, the host)
+        continues only when rank dst holds the data"""
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+
+    def assembled(self):
+        """{name: [batch, ...]} in global problem order from the receive buffers (rank dst; after finish())"""
         out = {}
         for name, whole in self.recv.items():
             tail = tuple(whole.shape[2:])

@@ -13,10 +13,10 @@
 // and the 16 lanes of a row write 128 contiguous bytes of the column-major C.
 //
 // DSYEV: cyclic two-sided Jacobi with the round-robin (tournament) ordering: a step applies n/2 disjoint rotations at
-// once, A <- J^T (A J), V <- V J; a sweep is n - 1 steps.  Two launches per step:
-//   jacobi_cols: B = A J (+ V = V J in place): one thread per (row, pair); every thread forms its pair's rotation from
-//                a_pp, a_qq, a_pq of the unmodified A (reads only) and the rotation is kept for the second launch;
-//   jacobi_rows: A = J^T B: one workgroup per column, which is staged in LDS so that global accesses stay contiguous.
+// once, A <- J^T (A J), V <- V J; a sweep is n - 1 steps.  ONE launch per step (jacobi_step_kernel): the workgroup of a
+// pair stages its two columns in LDS, applies the previous step's pending row rotations to them, forms its own rotation
+// from the finished 2x2 block and writes the rotated columns (and V's) in place; jacobi_rows applies the last pending
+// row rotations once per sweep, for the convergence test.
 // Converged when the off-diagonal norm is below eps * the Frobenius norm (checked once per sweep).  Jacobi's
 // eigenvalues are at least as accurate as the QR iteration's behind LAPACK's dsyev; eigenvectors are defined up to
 // sign, like LAPACK's.
@@ -206,37 +206,6 @@ __device__ __forceinline__ void jacobi_rotation(double app, double aqq, double a
     s = t * c;
 }
 
-// B = A J, V = V J (in place); cs[2k], cs[2k+1] = rotation of pair k.  grid (ceil(n/256), n2/2), block 256
-__global__ __launch_bounds__(256) void jacobi_cols_kernel(int n, int n2, int step, const double *A, double *Bm, double *V,
-                                                          int ld, double *cs, int want_vectors)
-{
-    const int k = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-    int p, q;
-    jacobi_pair(n2, step, k, p, q);
-    if (q >= n) { // the padding player of an odd n: its partner's column is copied unchanged
-        if (i < n && p < n) Bm[(size_t)p * ld + i] = A[(size_t)p * ld + i];
-        if (i == 0) {
-            cs[2 * k] = 1.0;
-            cs[2 * k + 1] = 0.0;
-        }
-        return;
-    }
-    double c, s;
-    jacobi_rotation(A[(size_t)p * ld + p], A[(size_t)q * ld + q], A[(size_t)q * ld + p], c, s);
-    if (i == 0) {
-        cs[2 * k] = c;
-        cs[2 * k + 1] = s;
-    }
-    if (i >= n) return;
-    const double ap = A[(size_t)p * ld + i], aq = A[(size_t)q * ld + i];
-    Bm[(size_t)p * ld + i] = c * ap - s * aq;
-    Bm[(size_t)q * ld + i] = s * ap + c * aq;
-    if (want_vectors) {
-        const double vp = V[(size_t)p * ld + i], vq = V[(size_t)q * ld + i];
-        V[(size_t)p * ld + i] = c * vp - s * vq;
-        V[(size_t)q * ld + i] = s * vp + c * vq;
-    }
-}
 // A = J^T B: column j staged in LDS (dynamic: n doubles), one thread per pair.  grid n, block 256
 __global__ __launch_bounds__(256) void jacobi_rows_kernel(int n, int n2, int step, const double *Bm, double *A, int ld,
                                                           const double *cs)
@@ -256,6 +225,73 @@ __global__ __launch_bounds__(256) void jacobi_rows_kernel(int n, int n2, int ste
     }
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += 256) A[(size_t)j * ld + i] = col[i];
+}
+// One launch per step (round 2): with B_t = A_{t-1} J_t and A_t = J_t^T B_t, the next step's column pass needs of A_t
+// only the two columns of its own pair -- B_{t+1}[:, {p,q}] = (J_t^T B_t)[:, {p,q}] J_{t+1} -- so the workgroup of pair
+// (p, q) stages B_t's columns p, q in LDS, applies the PREVIOUS step's row rotations to them (rotations from cs_prev),
+// forms its own rotation from the finished 2x2 block and writes the rotated columns back in place (the pairs of a
+// step are disjoint).  A itself is materialised only where the convergence test wants it (jacobi_rows_kernel).  Same
+// arithmetic per element as the two-pass form; half the launches and half the traffic.
+// grid n2/2, block 256, dynamic LDS 2 n doubles.  prev_step < 0: no rotation pending (the first step).
+__global__ __launch_bounds__(256) void jacobi_step_kernel(int n, int n2, int prev_step, int step, double *Bm, double *V, int ld,
+                                                          const double *cs_prev, double *cs_next, int want_vectors)
+{
+    extern __shared__ double col[];
+    double *cp = col, *cq = col + n;
+    const int k = blockIdx.x;
+    int p, q;
+    jacobi_pair(n2, step, k, p, q);
+    const bool has_q = q < n; // (q = n: the padding player of an odd n -- column p only takes the pending row rotations)
+    double *gp = Bm + (size_t)p * ld, *gq = Bm + (size_t)(has_q ? q : p) * ld;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        cp[i] = gp[i];
+        if (has_q) cq[i] = gq[i];
+    }
+    __syncthreads();
+    if (prev_step >= 0) {
+        for (int kk = threadIdx.x; kk < n2 / 2; kk += 256) {
+            int pp, qq;
+            jacobi_pair(n2, prev_step, kk, pp, qq);
+            if (qq >= n) continue;
+            const double c = cs_prev[2 * kk], s = cs_prev[2 * kk + 1];
+            const double bp = cp[pp], bq = cp[qq];
+            cp[pp] = c * bp - s * bq;
+            cp[qq] = s * bp + c * bq;
+            if (has_q) {
+                const double dp = cq[pp], dq = cq[qq];
+                cq[pp] = c * dp - s * dq;
+                cq[qq] = s * dp + c * dq;
+            }
+        }
+        __syncthreads();
+    }
+    if (!has_q) {
+        for (int i = threadIdx.x; i < n; i += 256) gp[i] = cp[i];
+        if (threadIdx.x == 0) {
+            cs_next[2 * k] = 1.0;
+            cs_next[2 * k + 1] = 0.0;
+        }
+        return;
+    }
+    double c, s;
+    jacobi_rotation(cp[p], cq[q], cq[p], c, s);
+    if (threadIdx.x == 0) {
+        cs_next[2 * k] = c;
+        cs_next[2 * k + 1] = s;
+    }
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const double ap = cp[i], aq = cq[i];
+        gp[i] = c * ap - s * aq;
+        gq[i] = s * ap + c * aq;
+    }
+    if (want_vectors) {
+        double *vp = V + (size_t)p * ld, *vq = V + (size_t)q * ld;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const double a = vp[i], b = vq[i];
+            vp[i] = c * a - s * b;
+            vq[i] = s * a + c * b;
+        }
+    }
 }
 // out[0] = sum of squares of the strictly lower triangle, out[1] = of the diagonal (atomics: a convergence test only)
 __global__ __launch_bounds__(256) void jacobi_norms_kernel(int n, const double *A, int ld, double *out)
@@ -339,7 +375,7 @@ size_t fl_dsyev_workspace_bytes(int n)
 {
     if (n <= 0) return 0;
     const size_t n2 = (size_t)n + (n & 1);
-    return ((size_t)2 * n * n + n2 + 4) * sizeof(double); // B, V, rotations, norms
+    return ((size_t)2 * n * n + 2 * n2 + 4) * sizeof(double); // A_t, V, rotations of two steps, norms
 }
 
 // A_dev: n x n column-major (lda), lower triangle referenced; on return the diagonal of the rotated matrix is in w_dev
@@ -358,21 +394,31 @@ int fl_dsyev_jacobi(char jobz, int n, double *A_dev, int lda, double *w_dev, voi
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int want = (jobz == 'V' || jobz == 'v') ? 1 : 0;
     const int n2 = n + (n & 1);
-    double *Bm = static_cast<double *>(workspace_dev), *V = Bm + (size_t)n * n, *cs = V + (size_t)n * n, *nrm = cs + n2;
+    double *Am = static_cast<double *>(workspace_dev), *V = Am + (size_t)n * n, *cs = V + (size_t)n * n, *nrm = cs + 2 * n2;
+    const size_t lds_step = (size_t)2 * n * sizeof(double);
+    if (lds_step > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(fl::jacobi_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_step) != hipSuccess)
+        return FL_ERR_LAUNCH;
     hipLaunchKernelGGL(fl::jacobi_init_kernel, dim3(n), dim3(256), 0, st, n, A_dev, V, n);
-    int sweeps = 0;
+    int sweeps = 0, prev = -1, cur = 0;
     bool done = (n == 1);
     double h[2], off_prev = -1.0;
+    if (done && hipMemcpyAsync(Am, A_dev, sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) return FL_ERR_LAUNCH;
     while (!done && sweeps < max_sweeps) {
+        // A_dev holds B_t (the column-rotated matrix whose row rotations, cs[cur ^ 1], are still pending)
         for (int step = 0; step < n2 - 1; ++step) {
-            hipLaunchKernelGGL(fl::jacobi_cols_kernel, dim3((n + 255) / 256, n2 / 2), dim3(256), 0, st, n, n2, step, A_dev, Bm,
-                               V, n, cs, want);
-            hipLaunchKernelGGL(fl::jacobi_rows_kernel, dim3(n), dim3(256), (size_t)n * sizeof(double), st, n, n2, step, Bm,
-                               A_dev, n, cs);
+            hipLaunchKernelGGL(fl::jacobi_step_kernel, dim3(n2 / 2), dim3(256), lds_step, st, n, n2, prev, step, A_dev, V, n,
+                               cs + (size_t)(cur ^ 1) * n2, cs + (size_t)cur * n2, want);
+            prev = step;
+            cur ^= 1;
         }
         ++sweeps;
+        // A_t = J_t^T B_t, materialised beside B_t for the convergence test (and the final diagonal)
+        hipLaunchKernelGGL(fl::jacobi_rows_kernel, dim3(n), dim3(256), (size_t)n * sizeof(double), st, n, n2, prev, A_dev, Am,
+                           n, cs + (size_t)(cur ^ 1) * n2);
         if (hipMemsetAsync(nrm, 0, 2 * sizeof(double), st) != hipSuccess) return FL_ERR_LAUNCH;
-        hipLaunchKernelGGL(fl::jacobi_norms_kernel, dim3(n), dim3(256), 0, st, n, A_dev, n, nrm);
+        hipLaunchKernelGGL(fl::jacobi_norms_kernel, dim3(n), dim3(256), 0, st, n, Am, n, nrm);
         if (hipMemcpyAsync(h, nrm, sizeof h, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
             return FL_ERR_LAUNCH;
         // off(A) <= n eps ||A||_F -- the level rounding keeps the off-diagonal part at (every element is rotated ~n times
@@ -382,7 +428,10 @@ int fl_dsyev_jacobi(char jobz, int n, double *A_dev, int lda, double *w_dev, voi
         done = off2 <= tol * tol * fro2 || (off_prev >= 0.0 && off2 <= 1e-24 * fro2 && off2 > 0.25 * off_prev);
         off_prev = off2;
     }
-    hipLaunchKernelGGL(fl::jacobi_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, A_dev, n, w_dev);
+    if (sweeps == 0 && n > 1 && // max_sweeps <= 0: the diagonal of the matrix as given
+        hipMemcpyAsync(Am, A_dev, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return FL_ERR_LAUNCH;
+    hipLaunchKernelGGL(fl::jacobi_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, Am, n, w_dev);
     if (sweeps_out) *sweeps_out = done ? sweeps : -sweeps;
     return fl::launch_status();
 }

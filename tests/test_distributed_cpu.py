@@ -42,6 +42,13 @@ def _worker(rank, world, port, B, n, ret, interleaved):
     mine = {k: torch.from_numpy(np.ascontiguousarray(r[k])) for k in ("x", "f", "iters", "status")}
     for _ in range(2):  # the buffers are reused from step to step
         res = G.gather(mine)
+    # the overlapped form bench.py's timed step uses: enqueue, (next solve would run here), finish, read
+    assert G.gather(mine, overlap=True) is None
+    assert G.gather(mine, overlap=True) is None  # a second exchange first waits for the one in flight
+    G.finish()
+    if rank == 0:
+        late = G.assembled()
+        assert all(torch.equal(late[k], res[k]) for k in ("x", "f", "iters", "status"))
     dist.barrier()
     if rank == 0:
         assert res["x"].shape == (B, n)
