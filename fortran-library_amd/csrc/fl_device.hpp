@@ -416,6 +416,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
     double miu, cc;
     int outer_it, inner_iters_total;
     int blk[AUG ? EPT : 1]; // constraint block of each of the thread's elements (-1 = padding)
+    int cshift;             // log2 of the lanes per constraint block where blocks are aligned lane groups (4, 5, 6), else 0
 
     enum { PH_INIT = 0, PH_LS = 1, PH_DONE = 2, PH_HESS = 3 };
     // internal continuations of advance() (they never leave it): every continuation is inlined ONCE and the
@@ -515,9 +516,11 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
         inner_iters_total = 0;
         cc = 0.0;
         miu = 0.0;
+        cshift = 0;
         if constexpr (AUG) {
             if constexpr (OBJ != FL_OBJ_EXTERNAL) { // the built-in constraint family: block spheres
                 const int w = n / A.aug_m;
+                if (w > 0 && (2 * G::T) % w == 0) cshift = (w == 128) ? 6 : (w == 64 ? 5 : (w == 32 ? 4 : 0));
 #pragma unroll
                 for (int k = 0; k < EPT; ++k) {
                     const int e = G::e0(k >> 1) + (k & 1);
@@ -576,7 +579,23 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
             double r2[2] = {r[0], r[1]};
             double *cxs = lds + L_CX;
             __syncthreads(); // readers of the previous trial's c(x) are done
-            if (NW < 8 && m <= 8) { // the objective's two sums and up to 8 constraints in ONE reduction phase
+            if (cshift) {
+                // Blocks that coincide with aligned groups of 16 / 32 / 64 lanes of one chunk (block width 32 / 64 /
+                // 128; C5: n = 512, 8 blocks of 64): the masked full-width sum of block j only ever adds exact zeros
+                // outside its group, so the same bits come from the group's own levels of the reduction tree -- one
+                // short reduction per chunk instead of one full-width reduction per constraint.
+                const int tl = G::tid();
+#pragma unroll
+                for (int c = 0; c < G::NCH; ++c) {
+                    double v = x[2 * c] * x[2 * c] + x[2 * c + 1] * x[2 * c + 1];
+                    if (cshift == 6) v = wave_allreduce(v);
+                    else if (cshift == 5) v = row_allreduce(fold16(v, v));
+                    else v = row_allreduce(v);
+                    const int j = c * (G::T >> cshift) + (tl >> cshift);
+                    if ((tl & ((1 << cshift) - 1)) == 0 && j < m) cxs[j] = v - 1.0;
+                }
+                R.run(r2); // (its barrier also publishes c(x))
+            } else if (NW < 8 && m <= 8) { // the objective's two sums and up to 8 constraints in ONE reduction phase
                                     // (not in the 512-thread kernels: ten values at once cost them spills; every value's
                                     // sum has the same order either way)
                 double q[10];
@@ -607,7 +626,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
                     }
                 }
             }
-            __syncthreads();
+            if (!cshift) __syncthreads();
             // L = f - lambda.c + miu/2 c.c (NO.f90:2198); v = miu*c - lambda (NO.f90:2205)
             double lc = 0.0, c2 = 0.0;
             for (int j = 0; j < m; ++j) {
