@@ -331,11 +331,11 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
     static constexpr int L_RHO = L_RED + 2 * Reducer<NW>::NVMAX * NW;
     static constexpr int L_ALPHA = L_RHO + FL_MAX_MEMORY;
     static constexpr int L_LAM = L_ALPHA + FL_MAX_MEMORY;        // lambda[FL_MAX_CONSTRAINTS]
-    static constexpr int L_CX = L_LAM + FL_MAX_CONSTRAINTS;      // c(x)[FL_MAX_CONSTRAINTS]
+    static constexpr int L_CX = L_LAM + FL_MAX_CONSTRAINTS;      // c(x)[2][FL_MAX_CONSTRAINTS]
     // scratch of the Cholesky kernels (pivot and multipliers of a block: 2 + BW doubles).  Its own slot: with the
     // augmented Lagrangian around NewtonRaphson / exact BFGS, c(x) must survive the factorisation (inner_finished reads
     // it when the inner solver stops on MaxIteration right after a direction)
-    static constexpr int L_SLOT = L_CX + FL_MAX_CONSTRAINTS;
+    static constexpr int L_SLOT = L_CX + 2 * FL_MAX_CONSTRAINTS; // (c(x) is double buffered: cx_ptr())
     static constexpr int L_XS = (L_SLOT + 16 + 1) & ~1;
     static constexpr int L_G0 = (L_XS + (Obj::LDS_DOUBLES > 0 ? Obj::LDS_DOUBLES : 0) + 1) & ~1;
     // BFGS: s, q, g broadcast arrays; the first one doubles as the g_old parking slot (the
@@ -416,6 +416,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
     double miu, cc;
     int outer_it, inner_iters_total;
     int blk[AUG ? EPT : 1]; // constraint block of each of the thread's elements (-1 = padding)
+    int cpar;               // which of the two c(x) buffers holds the last evaluation's constraints
     int cshift;             // log2 of the lanes per constraint block where blocks are aligned lane groups (4, 5, 6), else 0
 
     enum { PH_INIT = 0, PH_LS = 1, PH_DONE = 2, PH_HESS = 3 };
@@ -446,6 +447,11 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
     }
     // LDS rows of the slot-th pair of the LDS ring (s row, then y row)
     __device__ __forceinline__ double *lds_pair(int slot) const { return lds + L_G0 + (size_t)(2 * slot) * NPAD; }
+    // c(x) of the last evaluation.  Two buffers: where the constraints are reduced per lane group (evaluate()), a trial
+    // writes the buffer the previous trial did not use, so the only barrier of a trial is the objective reduction's --
+    // a wave still reading trial k's c(x) cannot be overtaken by trial k + 1's writers, and trial k + 2's have passed
+    // trial k + 1's barrier.
+    __device__ __forceinline__ double *cx_ptr() const { return lds + L_CX + cpar * FL_MAX_CONSTRAINTS; }
     // where g_old waits during the line search (BFGS: in the second broadcast array -- the first one is the row
     // buffer of the Cholesky kernels, which may run before g_old is wanted)
     __device__ __forceinline__ double *g0_park() const
@@ -517,6 +523,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
         cc = 0.0;
         miu = 0.0;
         cshift = 0;
+        cpar = 0;
         if constexpr (AUG) {
             if constexpr (OBJ != FL_OBJ_EXTERNAL) { // the built-in constraint family: block spheres
                 const int w = n / A.aug_m;
@@ -577,8 +584,9 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
                 return acc;
             };
             double r2[2] = {r[0], r[1]};
-            double *cxs = lds + L_CX;
-            __syncthreads(); // readers of the previous trial's c(x) are done
+            if (cshift) cpar ^= 1; // (no barrier: the other buffer's readers are a whole trial behind, see cx_ptr())
+            else __syncthreads();  // readers of the previous trial's c(x) are done
+            double *cxs = cx_ptr();
             if (cshift) {
                 // Blocks that coincide with aligned groups of 16 / 32 / 64 lanes of one chunk (block width 32 / 64 /
                 // 128; C5: n = 512, 8 blocks of 64): the masked full-width sum of block j only ever adds exact zeros
@@ -679,7 +687,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
                                                       const double *cd_user, double &f, double &gp, double &ggo)
     {
         const int m = A.aug_m;
-        double *cxs = lds + L_CX;
+        double *cxs = cx_ptr();
         __syncthreads(); // readers of the previous c(x) are done
         const int tl = G::tid();
         if (tl < m) cxs[tl] = c_user[tl];
@@ -850,7 +858,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
             // block j, so column j gets 2 v_b on the diagonal and (2 x_i)(2 x_j) on the rows of its block b.
             // c(x) of the last evaluation (= the current x) is in LDS; x is staged in the first row buffer.
             double *xstage = lds + L_BF;
-            const double *cxs = lds + L_CX;
+            const double *cxs = cx_ptr();
             __syncthreads();
             store_pad<NW, EPT>(xstage, x);
             __syncthreads();
@@ -1044,7 +1052,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
         if constexpr (AUG) {
             // call c(cx,x,M,N): cx of the last evaluation is c(x) (x is the last evaluated point)
             const int m = A.aug_m;
-            double *cxs = lds + L_CX;
+            double *cxs = cx_ptr();
             double c2 = 0.0;
             for (int j = 0; j < m; ++j) c2 = c2 + cxs[j] * cxs[j];
             cc = uni(c2);

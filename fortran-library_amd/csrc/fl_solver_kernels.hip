@@ -14,16 +14,29 @@
 #include "fl_host.hpp"
 #include "fl_big.hpp"
 
-#ifdef FL_MIN_WPE
-#define FL_OCC_ATTR __attribute__((amdgpu_waves_per_eu(FL_MIN_WPE)))
-#else
-#define FL_OCC_ATTR
-#endif
 
 namespace fl {
 
+// occupancy the register allocator is held to (waves per SIMD).  The augmented-Lagrangian L-BFGS / CG kernels at 4
+// elements per thread are bound by the latency of their ~45 objective-only trials per gradient (C5): 130 VGPRs gave
+// 3 waves, capped at 128 they run 4.
+template <int NW, int EPT, int OBJ, int METHOD, int AUG> constexpr int min_waves_per_simd()
+{
+#ifdef FL_MIN_WPE
+    return FL_MIN_WPE;
+#else
+    // (the quartic / Rosenbrock instances would spill 10-14 VGPRs under the cap: left alone)
+    if (AUG && EPT == 4 && NW <= 2 && OBJ == FL_OBJ_DIAGQUAD && (METHOD == FL_SOLVER_LBFGS || METHOD == FL_SOLVER_CG)) return 4;
+    // (SD / CG at 8 elements per thread, 139-143 VGPRs as allocated freely, spill 15-84 under the same cap: left alone)
+    // L-BFGS on them at 4 elements per thread (n <= 512): 134-135
+    if (!AUG && OBJ == FL_OBJ_DIAGQUAD && EPT == 4 && METHOD == FL_SOLVER_LBFGS) return 4;
+    return 1;
+#endif
+}
+
 template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = 0>
-__global__ __launch_bounds__(NW * 64) FL_OCC_ATTR void fl_solve_kernel(SolveArgs A)
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(min_waves_per_simd<NW, EPT, OBJ, METHOD, AUG>())))
+void fl_solve_kernel(SolveArgs A)
 {
     using S = Solver<NW, EPT, OBJ, METHOD, AUG, EXACT>;
 #ifndef FL_LDS_PAD // tuning knob: extra LDS per workgroup caps the workgroups resident per CU
