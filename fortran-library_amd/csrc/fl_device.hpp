@@ -390,7 +390,17 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
 #endif
     static constexpr int BF_DEFER = (METHOD == FL_SOLVER_BFGS && OBJ != FL_OBJ_EXTERNAL && NPAD >= 2048) ? FL_BFGS_DEFER : 0;
     static constexpr int BF_FOLD_COLS = 128; // columns whose s_l[j], q_l[j] are staged in LDS at a time while folding
-    static constexpr int LDS_TOTAL = L_DEF + 2 * BF_DEFER;
+    // SD / CG on the diagonal quadratics at 8 elements per thread (C3: no history, nothing streams from HBM, the trials'
+    // latency is all there is): the line search's x0 waits in an LDS row of its own -- one read per trial, every thread
+    // reads back what it wrote -- which brings the kernel from 141 to <= 128 VGPRs = 4 waves per SIMD instead of 3
+    // (fl_solver_kernels.hip: min_waves_per_simd).
+#ifndef FL_X0_LDS
+#define FL_X0_LDS 1
+#endif
+    static constexpr bool X0_LDS = FL_X0_LDS && (METHOD == FL_SOLVER_SD || METHOD == FL_SOLVER_CG) && !AUG &&
+                                   OBJ == FL_OBJ_DIAGQUAD && EPT == 8;
+    static constexpr int L_X0 = L_DEF + 2 * BF_DEFER;
+    static constexpr int LDS_TOTAL = L_X0 + (X0_LDS ? NPAD : 0);
     using DN = Dense<NW, EPT>;
 
     const SolveArgs &A;
@@ -398,7 +408,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
     int prob, n;
     Reducer<NW> R;
     Obj obj;
-    double x[EPT], g[EPT], p[EPT], x0[EPT];
+    double x[EPT], g[EPT], p[EPT], x0[X0_LDS ? 1 : EPT];
     // uniform scalars
     double fnew, gg, pp, phid, phidold, a;
     int iters, nf, ng, status, phase, pending;
@@ -550,8 +560,15 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
     // ---------------------------------------------------------------- evaluation (built-in objectives)
     __device__ __forceinline__ void move(double at)
     {
+        if constexpr (X0_LDS) {
+            double t[EPT];
+            load_pad<NW, EPT>(lds + L_X0, t);
 #pragma unroll
-        for (int k = 0; k < EPT; ++k) x[k] = x0[k] + at * p[k];
+            for (int k = 0; k < EPT; ++k) x[k] = t[k] + at * p[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) x[k] = x0[k] + at * p[k];
+        }
     }
     // f, g.p, g.g at x; with AUG the objective is the augmented Lagrangian
     // WANT_G = false (augmented Lagrangian only): an objective-only trial -- the reference's shrink loop
@@ -789,8 +806,12 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
             }
             fused = fused && in_main;
         }
+        if constexpr (X0_LDS) {
+            store_pad<NW, EPT>(lds + L_X0, x); // xold=x (doubles as the line search's x0)
+        } else {
 #pragma unroll
-        for (int k = 0; k < EPT; ++k) x0[k] = x[k]; // xold=x (doubles as the line search's x0)
+            for (int k = 0; k < EPT; ++k) x0[k] = x[k];
+        }
         if constexpr (NEEDS_G0) store_pad<NW, EPT>(g0_park(), g); // fdold=fdnew, parked in LDS
         phidold = phid;
         const int strong = (METHOD == FL_SOLVER_CG && A.cg_method == FL_CG_PR) ? 1 : A.strong;

@@ -27,7 +27,8 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> constexpr int min_waves
 #else
     // (the quartic / Rosenbrock instances would spill 10-14 VGPRs under the cap: left alone)
     if (AUG && EPT == 4 && NW <= 2 && OBJ == FL_OBJ_DIAGQUAD && (METHOD == FL_SOLVER_LBFGS || METHOD == FL_SOLVER_CG)) return 4;
-    // (SD / CG at 8 elements per thread, 139-143 VGPRs as allocated freely, spill 15-84 under the same cap: left alone)
+    // SD / CG on them at 8 elements per thread, x0 in LDS (Solver::X0_LDS)
+    if (!AUG && OBJ == FL_OBJ_DIAGQUAD && EPT == 8 && (METHOD == FL_SOLVER_SD || METHOD == FL_SOLVER_CG) && FL_X0_LDS) return 4;
     // L-BFGS on them at 4 elements per thread (n <= 512): 134-135
     if (!AUG && OBJ == FL_OBJ_DIAGQUAD && EPT == 4 && METHOD == FL_SOLVER_LBFGS) return 4;
     return 1;
