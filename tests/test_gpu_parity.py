@@ -479,8 +479,8 @@ def _gpu_auglag(solver_name, kind, x0, m, d=None, b=None, miu0=1.0, **kw):
     ("ConjugateGradient", O.CG, O.DIAGQUAD, 512, 8, {"Precision": 1e-8, "MaxIteration": 200}),
     ("LBFGS", O.LBFGS, O.ROSENBROCK, 96, 3, {"Precision": 1e-9, "Memory": 5}),
     # blocks = aligned groups of 64 lanes (width 128: the per-chunk reductions over one wave), 2 and 4 waves
-    ("LBFGS", O.LBFGS, O.DIAGQUAD, 1024, 8, {"Precision": 1e-8, "MaxIteration": 60}),
-    ("ConjugateGradient", O.CG, O.DIAGQUAD, 2048, 16, {"Precision": 1e-8, "MaxIteration": 40}),
+    ("LBFGS", O.LBFGS, O.DIAGQUAD, 1024, 8, {"Precision": 1e-8, "MaxIteration": 12}),
+    ("ConjugateGradient", O.CG, O.DIAGQUAD, 2048, 16, {"Precision": 1e-8, "MaxIteration": 8}),
 ])
 def test_augmented_lagrangian_bitexact(solver_name, solver, kind, n, m, kw):
     NLO = _nlo()
