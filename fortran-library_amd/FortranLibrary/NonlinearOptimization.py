@@ -323,7 +323,7 @@ def minimize_rci(solver, x, fun, options=None, max_steps=10000000, check_every=8
 def minimize_rci_auglag(solver, x, fun, M, lambda0=None, miu0=1.0, options=None, max_steps=10000000, check_every=8, **kw):
     """AugmentedLagrangian (NO.f90:2005) for a batch with the caller's objective AND equality constraints, by reverse
     communication: `fun(x)` returns (f[batch], g[batch, n], c[batch, M], cd[batch, M, n]) CUDA tensors for the whole
-    batch (cd[k, j] = grad c_j at x_k).  solver: LBFGS_ | CG (the inner solver).  x is updated in place; returns the
+    batch (cd[k, j] = grad c_j at x_k).  solver: LBFGS_ | CG | BFGS_ with ExactStep <= 0 (the inner solver).  x is updated in place; returns the
     usual outputs plus "lambda" [batch, M], "cnorm2", "outer"."""
     import torch
     o = options if options is not None else default_options(solver, **kw)

@@ -206,8 +206,10 @@ static void launch_rci(Rci *h, const double *f, const double *g, const double *c
 #define FL_RCI_AUG(M)                                                                                             \
     hipLaunchKernelGGL((rci_step_kernel<NW, EPT, M, 1>), grid, block, 0, h->stream, h->A, h->first, h->sc, h->vec, \
                        h->rho, f, g, c, cd, req)
-    if (h->aug) { // AugmentedLagrangian around L-BFGS (NO.f90:2150-2167) or ConjugateGradient (2168-2185)
+    if (h->aug) { // AugmentedLagrangian around L-BFGS (NO.f90:2150-2167), ConjugateGradient (2168-2185) or quasi-Newton
+                  // BFGS (2131-2148 with ExactStep <= 0: every outer round rebuilds H from a I)
         if (h->solver == FL_SOLVER_CG) FL_RCI_AUG(FL_SOLVER_CG);
+        else if (h->solver == FL_SOLVER_BFGS) FL_RCI_AUG(FL_SOLVER_BFGS);
         else FL_RCI_AUG(FL_SOLVER_LBFGS);
         return;
     }
@@ -363,12 +365,15 @@ int fl_rci_step(fl_rci *h, double *x_dev, const double *f_dev, const double *g_d
 }
 
 // AugmentedLagrangian (NO.f90:2005-2241) for a batch with the CALLER's objective and constraints: create a handle
-// around the inner solver (FL_SOLVER_LBFGS | FL_SOLVER_CG), then step it like fl_rci_step with, in addition,
+// around the inner solver (FL_SOLVER_LBFGS | FL_SOLVER_CG | FL_SOLVER_BFGS with exact_step <= 0), then step it like fl_rci_step with, in addition,
 // c_dev [batch][m] = c(x) and cd_dev [batch][m][n] = the constraint Jacobian (row j = grad c_j; Fortran cdx(N,M)).
 int fl_rci_create_auglag(fl_rci **out, int solver, int batch, int n, int m, double *lambda_dev, double miu0,
                          const fl_options *opt, void *stream)
 {
-    if (solver != FL_SOLVER_LBFGS && solver != FL_SOLVER_CG) return FL_ERR_INVALID_ARGUMENT;
+    if (solver != FL_SOLVER_LBFGS && solver != FL_SOLVER_CG && solver != FL_SOLVER_BFGS) return FL_ERR_INVALID_ARGUMENT;
+    // BFGS: quasi-Newton updates only -- the exact inverse Hessian of L (NO.f90:2229-2241) needs f'' and every c_j'',
+    // which this protocol does not carry (the fused kernel and the one-problem legacy symbol have that branch)
+    if (solver == FL_SOLVER_BFGS && (!opt || opt->exact_step > 0)) return FL_ERR_INVALID_ARGUMENT;
     if (m < 1 || m > FL_MAX_CONSTRAINTS || !lambda_dev) return FL_ERR_INVALID_ARGUMENT;
     if (n > 4096) return FL_ERR_UNSUPPORTED_SIZE; // like fl_augmented_lagrangian_batched: the register path only
     const int rc = fl_rci_create(out, solver, batch, n, opt, stream);

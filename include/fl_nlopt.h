@@ -259,8 +259,9 @@ int fl_rci_destroy(fl_rci *handle);
 
 /* ---- AugmentedLagrangian (NO.f90:2005-2241) for a batch with the CALLER's objective AND constraints -------------
  * The reference's callbacks c(cx,x,M,N) and cd(cdx(N,M),x,M,N) (NO.f90:1928-1934) join the ask / tell loop: the handle
- * wraps the inner solver (FL_SOLVER_LBFGS, NO.f90:2150-2167, or FL_SOLVER_CG, 2168-2185; always with f_fd present like
- * the reference, 2153) in the outer loop lambda <- lambda - miu c, miu <- miu * Increment (2155-2157), per problem and
+ * wraps the inner solver (FL_SOLVER_LBFGS, NO.f90:2150-2167, FL_SOLVER_CG, 2168-2185, or FL_SOLVER_BFGS with
+ * opt->exact_step <= 0, 2131-2148: quasi-Newton updates, H rebuilt from a I in every outer round; always with f_fd
+ * present like the reference, 2153) in the outer loop lambda <- lambda - miu c, miu <- miu * Increment (2155-2157), per problem and
  * inside the step kernel.  Requests carry two more bits: FL_RCI_REQ_C (32) -- with EVERY request: c_dev[batch][m] =
  * c(x) at the requested point -- and FL_RCI_REQ_CD (64) -- with every gradient request: cd_dev[batch][m][n], row j =
  * grad c_j(x) (the Fortran array cdx(N,M) as it lies in memory).  L = f - lambda.c + miu/2 c.c and

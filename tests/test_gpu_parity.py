@@ -527,7 +527,10 @@ def test_augmented_lagrangian_config5_vs_reference_order():
     ("LBFGS", O.LBFGS, O.QUARTIC, 10, 1, 256, {"Precision": 1e-8}),  # test/test.f90:452-478 / test.cpp:112-125 as a batch
     ("LBFGS", O.LBFGS, O.DIAGQUAD, 48, 3, 64, {"Precision": 1e-7}),
     ("ConjugateGradient", O.CG, O.DIAGQUAD, 48, 3, 32, {"Precision": 1e-6, "MaxIteration": 100}),
-    ("LBFGS", O.LBFGS, O.ROSENBROCK, 96, 3, 16, {"Precision": 1e-7, "Memory": 5}),
+    ("LBFGS", O.LBFGS, O.ROSENBROCK, 96, 3, 16, {"Precision": 1e-7, "Memory": 5, "MaxIteration": 10}),  # (a host round trip per trial)
+    # quasi-Newton BFGS inside (NO.f90:2131-2148 with ExactStep = 0; the oracle in the rank-2 form of the kernels)
+    ("BFGS", O.BFGS, O.DIAGQUAD, 48, 3, 8, {"Precision": 1e-7, "ExactStep": 0, "MaxIteration": 6}),
+    ("BFGS", O.BFGS, O.ROSENBROCK, 96, 3, 4, {"Precision": 1e-6, "ExactStep": 0, "MaxIteration": 5}),
 ])
 def test_augmented_lagrangian_batch_with_the_callers_constraints_by_reverse_communication(solver_name, solver, kind, n, m, B, kw):
     """AugmentedLagrangian for a batch (up to 256) with f, grad f, c AND cd coming from the caller (fl_rci_*_auglag: the
@@ -559,9 +562,15 @@ def test_augmented_lagrangian_batch_with_the_callers_constraints_by_reverse_comm
                 torch.tensor(cd_h, device=dev))
 
     x = torch.tensor(x0, device=dev)
-    out = NLO.minimize_rci_auglag(NLO.LBFGS_ if solver == O.LBFGS else NLO.CG, x, fun, m, check_every=1, **kw)
+    out = NLO.minimize_rci_auglag({O.LBFGS: NLO.LBFGS_, O.CG: NLO.CG, O.BFGS: NLO.BFGS_}[solver], x, fun, m, check_every=1, **kw)
     oo = _oracle_opts(solver, kw)
-    o = O.auglag_batch(solver, kind, x0, m, d=d, b=b, opts=oo, sum_mode=O.TREE, threads=T, ept=E)
+    if solver == O.BFGS:
+        oo.exact_step = 0
+        O.lib().flo_set_auglag_bfgs_form(1)
+    try:
+        o = O.auglag_batch(solver, kind, x0, m, d=d, b=b, opts=oo, sum_mode=O.TREE, threads=T, ept=E)
+    finally:
+        O.lib().flo_set_auglag_bfgs_form(0)
     g = {k: v.cpu().numpy() for k, v in out.items() if hasattr(v, "cpu")}
     assert np.array_equal(g["outer"], o["outer"])
     assert np.array_equal(g["iters"], o["iters"])
