@@ -333,6 +333,195 @@ __global__ void jacobi_diag_kernel(int n, const double *A, int ld, double *w)
     if (i < n) w[i] = A[(size_t)i * ld + i];
 }
 
+
+// ------------------------------------------------------------------ eigenvalues only: Householder tridiagonalisation + bisection
+// jobz = 'N' (LAPACK's dsyev does the same: dsytrd, then the tridiagonal's eigenvalues).  ONE launch per Householder
+// step: launch k applies the rank-2 update of step k-1 to the trailing columns, forms step k's reflector from the
+// updated column k and, in the same pass over each column, the product p_k = tau_k T_k v_k that step k+1's update needs
+// -- the trailing matrix is read and written once per step (16 m^2 bytes instead of 24 m^2 in three passes).  What is
+// O(m) -- w_{k-1} = p - (tau/2)(p.v) v, the updated column k, its norm, v_k -- every workgroup forms for itself in LDS
+// (two workgroup reductions), so nothing but the kernel boundary orders the steps.  A wave owns whole columns: the
+// product's dot is a wave reduction, no barrier in the column loop.  The full symmetric matrix is kept (both triangles
+// updated) so that every access is a contiguous column.
+//   vbuf / pbuf [2][n]: reflector and product of the previous / this step (double buffered), scal [2][2]: tau
+//   dyn. LDS: 3 n + 16 doubles (w_{k-1}, v_{k-1}, v_k, reduction scratch)
+__device__ __forceinline__ double wg256_sum(double v, double *scratch)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    __syncthreads(); // scratch free again
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+}
+__global__ __launch_bounds__(256) void tridiag_step_kernel(int n, int k, double *A, int ld, const double *vprev,
+                                                           const double *pprev, const double *tauprev, double *vnext,
+                                                           double *pnext, double *taunext, double *dvec, double *evec)
+{
+    extern __shared__ double tl[];
+    double *w = tl, *vv = tl + n, *vn = tl + 2 * n, *scr = tl + 3 * n;
+    const int tid = threadIdx.x, mp = n - k; // mp = length of the previous step's vectors (rows k .. n-1)
+    const bool first = (k == 0);
+    // 1. w_{k-1} = p + alpha v, alpha = -tau/2 (p.v)   (dsytd2)
+    double w0 = 0.0, v0 = 0.0;
+    if (!first) {
+        double s = 0.0;
+        for (int r = tid; r < mp; r += 256) {
+            const double vr = vprev[r];
+            vv[r] = vr;
+            s += pprev[r] * vr;
+        }
+        s = wg256_sum(s, scr);
+        const double alpha = -0.5 * tauprev[0] * s;
+        for (int r = tid; r < mp; r += 256) w[r] = pprev[r] + alpha * vv[r];
+        __syncthreads();
+        w0 = w[0];
+        v0 = vv[0];
+    }
+    // 2. column k after the update: d_k on the diagonal, x_k = rows k+1 .. n-1 below it -> reflector (dlarfg)
+    const double *colk = A + (size_t)k * ld;
+    const int m = n - k - 1; // rows / columns of the trailing matrix T_k
+    double nrm2 = 0.0;
+    for (int r = tid; r < m; r += 256) {
+        double x = colk[k + 1 + r];
+        if (!first) x = x - (vv[r + 1] * w0 + w[r + 1] * v0);
+        vn[r] = x;
+        if (r > 0) nrm2 += x * x;
+    }
+    nrm2 = wg256_sum(nrm2, scr);
+    const double alpha0 = vn[0];
+    double tau = 0.0, beta = alpha0, scale = 0.0;
+    if (nrm2 > 0.0) {
+        const double nr = sqrt(alpha0 * alpha0 + nrm2);
+        beta = alpha0 >= 0.0 ? -nr : nr;
+        tau = (beta - alpha0) / beta;
+        scale = 1.0 / (alpha0 - beta);
+    }
+    __syncthreads(); // every thread has read vn[0]
+    for (int r = tid; r < m; r += 256) vn[r] = (r == 0) ? 1.0 : vn[r] * scale;
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        for (int r = tid; r < m; r += 256) vnext[r] = vn[r];
+        if (tid == 0) {
+            double dk = colk[k];
+            if (!first) dk = dk - 2.0 * (v0 * w0);
+            dvec[k] = dk;
+            evec[k] = beta;
+            taunext[0] = tau;
+        }
+    }
+    // 3. the trailing columns: update of step k-1, stored, and their share of p_k = tau_k T_k v_k
+    const int lane = tid & 63, gw = blockIdx.x * 4 + (tid >> 6), nwv = gridDim.x * 4;
+    for (int c = gw; c < m; c += nwv) {
+        double *col = A + (size_t)(k + 1 + c) * ld + (k + 1);
+        const double wj = first ? 0.0 : w[c + 1], vj = first ? 0.0 : vv[c + 1];
+        double acc = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+        int r = lane;
+        for (; r + 192 < m; r += 256) { // four independent rows in flight per lane
+            double a0 = col[r], a1 = col[r + 64], a2 = col[r + 128], a3 = col[r + 192];
+            if (!first) {
+                a0 = a0 - (vv[r + 1] * wj + w[r + 1] * vj);
+                a1 = a1 - (vv[r + 65] * wj + w[r + 65] * vj);
+                a2 = a2 - (vv[r + 129] * wj + w[r + 129] * vj);
+                a3 = a3 - (vv[r + 193] * wj + w[r + 193] * vj);
+                col[r] = a0;
+                col[r + 64] = a1;
+                col[r + 128] = a2;
+                col[r + 192] = a3;
+            }
+            acc += a0 * vn[r];
+            acc1 += a1 * vn[r + 64];
+            acc2 += a2 * vn[r + 128];
+            acc3 += a3 * vn[r + 192];
+        }
+        for (; r < m; r += 64) {
+            double a = col[r];
+            if (!first) {
+                a = a - (vv[r + 1] * wj + w[r + 1] * vj);
+                col[r] = a;
+            }
+            acc += a * vn[r];
+        }
+        acc = (acc + acc1) + (acc2 + acc3);
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+        if (lane == 0) pnext[c] = tau * acc;
+    }
+}
+// lower triangle -> full symmetric matrix
+__global__ __launch_bounds__(256) void symmetrize_kernel(int n, double *A, int ld)
+{
+    const int j = blockIdx.x;
+    for (int i = threadIdx.x; i < j; i += 256) A[(size_t)j * ld + i] = A[(size_t)i * ld + j];
+}
+// Eigenvalues of the symmetric tridiagonal (d, e) by multisection with Sturm counts (LAPACK's dstebz counts the same
+// way): wave i finds eigenvalue i -- 64 sample points per pass, every lane one Sturm sequence, the bracket shrinks
+// 65-fold per pass.  count(x) = number of eigenvalues < x.  grid ceil(n / 4), block 256, dyn. LDS 2 n doubles.
+__global__ __launch_bounds__(256) void sturm_multisection_kernel(int n, const double *dvec, const double *evec,
+                                                                 const double *last_diag, double *wout)
+{
+    extern __shared__ double tl[];
+    double *d = tl, *e2 = tl + n;
+    __shared__ double red[3][4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    double gl = 1e308, gu = -1e308, emax = 0.0;
+    for (int i = tid; i < n; i += 256) {
+        const double di = (i == n - 1) ? last_diag[0] : dvec[i];
+        const double el = (i > 0) ? fabs(evec[i - 1]) : 0.0, er = (i < n - 1) ? fabs(evec[i]) : 0.0;
+        d[i] = di;
+        e2[i] = er * er; // e2[i] couples i and i+1
+        gl = fmin(gl, di - el - er);
+        gu = fmax(gu, di + el + er);
+        emax = fmax(emax, er * er);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        gl = fmin(gl, __shfl_xor(gl, o));
+        gu = fmax(gu, __shfl_xor(gu, o));
+        emax = fmax(emax, __shfl_xor(emax, o));
+    }
+    if (lane == 0) {
+        red[0][tid >> 6] = gl;
+        red[1][tid >> 6] = gu;
+        red[2][tid >> 6] = emax;
+    }
+    __syncthreads();
+    gl = fmin(fmin(red[0][0], red[0][1]), fmin(red[0][2], red[0][3]));
+    gu = fmax(fmax(red[1][0], red[1][1]), fmax(red[1][2], red[1][3]));
+    emax = fmax(fmax(red[2][0], red[2][1]), fmax(red[2][2], red[2][3]));
+    const double tnorm = fmax(fabs(gl), fabs(gu));
+    const double pivmin = 2.2250738585072014e-308 * fmax(1.0, emax);
+    const int idx0 = blockIdx.x * 4 + (tid >> 6);
+    if (gl == gu) { // a multiple of the identity (the zero matrix among them): exact
+        if (lane == 0 && idx0 < n) wout[idx0] = gl;
+        return;
+    }
+    // widen the Gershgorin interval a little so that both ends are strict bounds in floating point
+    gl = gl - 2.0 * tnorm * 2.220446049250313e-16 * n - 2.0 * pivmin;
+    gu = gu + 2.0 * tnorm * 2.220446049250313e-16 * n + 2.0 * pivmin;
+    const int idx = blockIdx.x * 4 + (tid >> 6); // this wave's eigenvalue (ascending, 0-based)
+    if (idx >= n) return;
+    double lo = gl, hi = gu;
+    for (int pass = 0; pass < 24; ++pass) {
+        const double width = hi - lo;
+        if (width <= 2.220446049250313e-16 * fmax(fabs(lo), fabs(hi)) + pivmin) break;
+        const double x = lo + width * ((double)(lane + 1) / 65.0);
+        double q = d[0] - x;
+        if (fabs(q) < pivmin) q = -pivmin;
+        int cnt = q < 0.0 ? 1 : 0;
+        for (int i = 1; i < n; ++i) {
+            q = d[i] - x - e2[i - 1] / q;
+            if (fabs(q) < pivmin) q = -pivmin;
+            cnt += q < 0.0 ? 1 : 0;
+        }
+        // lanes whose sample has at most idx eigenvalues below it lie left of eigenvalue idx (counts are monotone in
+        // exact arithmetic; the popcount is used, which is robust to a non-monotone pair)
+        const unsigned long long below = __ballot(cnt <= idx);
+        const int t = __popcll(below);
+        const double nlo = (t == 0) ? lo : __shfl(x, t - 1), nhi = (t == 64) ? hi : __shfl(x, t);
+        lo = nlo;
+        hi = nhi;
+    }
+    if (lane == 0) wout[idx] = 0.5 * (lo + hi);
+}
+
 } // namespace fl
 
 extern "C" {
@@ -433,6 +622,44 @@ int fl_dsyev_jacobi(char jobz, int n, double *A_dev, int lda, double *w_dev, voi
         return FL_ERR_LAUNCH;
     hipLaunchKernelGGL(fl::jacobi_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, Am, n, w_dev);
     if (sweeps_out) *sweeps_out = done ? sweeps : -sweeps;
+    return fl::launch_status();
+}
+
+
+// Eigenvalues only (jobz = 'N'): Householder tridiagonalisation in n - 1 launches, then multisection.  A_dev (n x n,
+// lda = n, lower triangle referenced) is destroyed; w_dev: the eigenvalues in ascending order.  n <= 6144 (three
+// vectors of the step live in LDS); workspace as for fl_dsyev_jacobi.
+int fl_dsyev_values(int n, double *A_dev, int lda, double *w_dev, void *workspace_dev, size_t workspace_bytes, void *stream)
+{
+    if (!A_dev || !w_dev || n <= 0 || lda != n) return FL_ERR_INVALID_ARGUMENT;
+    if (n > 6144) return FL_ERR_UNSUPPORTED_SIZE;
+    if (!workspace_dev || workspace_bytes < fl_dsyev_workspace_bytes(n)) return FL_ERR_WORKSPACE;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FL_ERR_NO_DEVICE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    double *ws = static_cast<double *>(workspace_dev);
+    double *vbuf = ws, *pbuf = ws + 2 * (size_t)n, *tau = ws + 4 * (size_t)n, *dvec = tau + 4, *evec = dvec + n;
+    const size_t lds_step = ((size_t)3 * n + 16) * sizeof(double), lds_sturm = (size_t)2 * n * sizeof(double);
+    if (lds_step > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(fl::tridiag_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_step) != hipSuccess)
+        return FL_ERR_LAUNCH;
+    if (lds_sturm > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(fl::sturm_multisection_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sturm) != hipSuccess)
+        return FL_ERR_LAUNCH;
+    hipLaunchKernelGGL(fl::symmetrize_kernel, dim3(n), dim3(256), 0, st, n, A_dev, n);
+    for (int k = 0; k + 1 < n; ++k) {
+        const int m = n - k - 1, cur = k & 1, prv = cur ^ 1;
+        int wgs = (m + 3) / 4; // a column per wave, at most two workgroups per CU (every workgroup repeats the O(m) part)
+        wgs = wgs < 1 ? 1 : (wgs > 512 ? 512 : wgs);
+        hipLaunchKernelGGL(fl::tridiag_step_kernel, dim3(wgs), dim3(256), lds_step, st, n, k, A_dev, n, vbuf + (size_t)prv * n,
+                           pbuf + (size_t)prv * n, tau + prv, vbuf + (size_t)cur * n, pbuf + (size_t)cur * n, tau + cur, dvec,
+                           evec);
+    }
+    // the last diagonal entry took its final update in the last step's column pass (n = 1: the matrix itself)
+    hipLaunchKernelGGL(fl::sturm_multisection_kernel, dim3((n + 3) / 4), dim3(256), lds_sturm, st, n, dvec, evec,
+                       A_dev + (size_t)(n - 1) * n + (n - 1), w_dev);
     return fl::launch_status();
 }
 

@@ -72,7 +72,10 @@ void __linearalgebra_MOD_my_dsyev(const char *jobtype, double *A, double *eigval
     const bool vec = jobtype && (*jobtype == 'V' || *jobtype == 'v');
     int sweeps = 0;
     bool ok = Ad.p && Wd.p && ws.p && hipMemcpy(Ad.p, A, a, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && fl_dsyev_jacobi(vec ? 'V' : 'N', n, Ad.as<double>(), n, Wd.as<double>(), ws.p, wsb, 60, &sweeps, nullptr) == FL_OK;
+    // eigenvalues only: tridiagonalisation + multisection (ascending already); with vectors, or beyond its size: Jacobi
+    const bool values_only = !vec && n <= 6144;
+    if (values_only) ok = ok && fl_dsyev_values(n, Ad.as<double>(), n, Wd.as<double>(), ws.p, wsb, nullptr) == FL_OK;
+    else ok = ok && fl_dsyev_jacobi(vec ? 'V' : 'N', n, Ad.as<double>(), n, Wd.as<double>(), ws.p, wsb, 60, &sweeps, nullptr) == FL_OK;
     std::vector<double> w(n), V;
     ok = ok && hipMemcpy(w.data(), Wd.p, sizeof(double) * n, hipMemcpyDeviceToHost) == hipSuccess;
     if (ok && vec) {

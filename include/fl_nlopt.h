@@ -194,6 +194,10 @@ int fl_dgemm(int transA, int M, int K, int N, const double *A_dev, int lda, cons
 size_t fl_dsyev_workspace_bytes(int n);
 int fl_dsyev_jacobi(char jobz, int n, double *A_dev, int lda, double *w_dev, void *workspace_dev, size_t workspace_bytes,
                     int max_sweeps, int *sweeps_out, void *stream);
+/* jobz = 'N' without the eigenvectors' cost (My_dsyev('N',...), LinearAlgebra.f90:879-887): Householder
+ * tridiagonalisation, one launch per reflector, then the tridiagonal's eigenvalues by multisection with Sturm counts;
+ * w_dev ascending, A_dev destroyed, n <= 6144, workspace fl_dsyev_workspace_bytes(n). */
+int fl_dsyev_values(int n, double *A_dev, int lda, double *w_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
 
 /* The BFGS inverse-Hessian update AS THE REFERENCE WRITES IT: U = I - rho y s^T, rho = 1/(y.s),
  * H <- matmul(transpose(U), matmul(H, U)) + rho s s^T  (NO.f90:958-962; LinearAlgebra.f90:105-114

@@ -199,3 +199,32 @@ def test_blocked_cholesky_large_matrices_against_lapack(n, B):
     for k in range(B):
         inv = Ad.cpu().numpy()[k, :, :n].T
         assert np.abs(inv @ As[k] - np.eye(n)).max() <= 1e-10
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 65, 130, 513])
+def test_my_dsyev_values_only_edge_cases(n):
+    """jobz = 'N' runs Householder tridiagonalisation + multisection (fl_dsyev_values): tiny and odd sizes, spectra with
+    multiplicities (identity, a projector), zero sub-columns (a matrix that is already tridiagonal / diagonal: reflectors
+    with tau = 0), graded entries.  Against numpy's LAPACK, to n eps ||A||."""
+    FL = _fl()
+    rng = np.random.default_rng(100 + n)
+    G = rng.standard_normal((n, n))
+    Q, _ = np.linalg.qr(G)
+    cases = {
+        "random": 0.5 * (G + G.T),
+        "identity": np.eye(n),
+        "diagonal": np.diag(np.arange(n, 0, -1.0)),
+        "tridiagonal": np.diag(np.full(n, 2.0)) + np.diag(np.full(max(n - 1, 0), -1.0), 1) + np.diag(np.full(max(n - 1, 0), -1.0), -1),
+        "projector": Q[:, : max(1, n // 3)] @ Q[:, : max(1, n // 3)].T,
+        "graded": (Q * np.logspace(0, -12, n)[None, :]) @ Q.T,
+        "zero": np.zeros((n, n)),
+    }
+    for name, A in cases.items():
+        A = 0.5 * (A + A.T)
+        S = np.asfortranarray(np.tril(A))
+        w = np.full(n, np.nan)
+        FL.__linearalgebra_MOD_my_dsyev(b"N", S.ctypes.data_as(dp), w.ctypes.data_as(dp), C.byref(C.c_int(n)), C.c_int(1))
+        ref = np.linalg.eigvalsh(A)
+        norm = max(np.abs(A).sum(axis=1).max(), 1e-300)
+        assert np.all(np.diff(w) >= 0), name
+        assert np.abs(w - ref).max() <= 4 * max(n, 4) * 2.3e-16 * norm + 1e-300, (name, np.abs(w - ref).max(), norm)
