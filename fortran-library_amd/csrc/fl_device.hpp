@@ -491,6 +491,20 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
 #ifndef FL_LAZY_GG
 #define FL_LAZY_GG 1
 #endif
+    // Wave priority (s_setprio).  Two waves share a SIMD: one is typically in the bulk arithmetic of a trial (independent
+    // multiplies / adds), the other somewhere in a serial chain -- a reduction, the scalar line-search step, the two-loop
+    // recursion with its row loads.  PRIO = 2 raises a wave's priority from a trial's reduction until the machine hands
+    // back the next request (line-search step, convergence tests, new direction) and drops it for the next trial's bulk
+    // part, so the chain -- and the recursion's loads -- never wait for the other wave's arithmetic.  Measured on the
+    // headline (profiles/r02/ab_prio.txt): 170.2 -> 164.3 ms; raised only over the line-search step: 165.4; only over the
+    // direction: 165.5; toggled around every reduction: 169.2.
+#ifndef FL_SETPRIO_LBFGS
+#define FL_SETPRIO_LBFGS 2
+#endif
+#ifndef FL_SETPRIO_OTHER
+#define FL_SETPRIO_OTHER 2 // (C2 2.85 -> 2.73 ms, C3 70.2 -> 65.8 ms, C5 348 -> 335 ms)
+#endif
+    static constexpr int PRIO = (OBJ == FL_OBJ_EXTERNAL) ? 0 : ((METHOD == FL_SOLVER_LBFGS && !AUG) ? FL_SETPRIO_LBFGS : FL_SETPRIO_OTHER);
     static constexpr bool LAZY_GG = FL_LAZY_GG && !AUG && OBJ != FL_OBJ_EXTERNAL;
 #ifndef FL_UNI_LEAN
 #define FL_UNI_LEAN 2
@@ -601,6 +615,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
                 return acc;
             };
             double r2[2] = {r[0], r[1]};
+            if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(3);
             if (cshift) cpar ^= 1; // (no barrier: the other buffer's readers are a whole trial behind, see cx_ptr())
             else __syncthreads();  // readers of the previous trial's c(x) are done
             double *cxs = cx_ptr();
@@ -677,12 +692,14 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
             // g.g is wanted once per line search (the convergence test after it), not per trial: advance() reduces it
             // when the search has ended -- 15 of the ~94 f64 operations of a trial
             double r3[3] = {r[0], r[1], dot_part<EPT>(g, p)};
+            if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(3);
             R.run(r3);
             f = uni(Obj::combine(r3[0], r3[1]));
             gp = uni(r3[2]);
         } else {
             r[2] = dot_part<EPT>(g, p);
             r[3] = dot_part<EPT>(g, g);
+            if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(3);
             R.run(r);
             f = uni(Obj::combine(r[0], r[1]));
             gp = uni(r[2]);
@@ -751,9 +768,11 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
             rq = (hess_stage == 0) ? GO_INIT_REST : GO_DIRECTION;
         } else {
             if constexpr (!LAZY_GG) gg = gg_new;
+            if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(3);
             rq = __builtin_amdgcn_readfirstlane(ls.step(fv, pv));
             ls.template uniformize<UNI_LEVEL>();
             if (rq == 0) {
+                if constexpr (PRIO == 6) __builtin_amdgcn_s_setprio(3);
                 if constexpr (LAZY_GG) gg = reduce_gg(); // x, g are those of the accepted point (the last evaluation)
                 rq = after_linesearch();
             }
@@ -783,6 +802,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
         if (rq == GO_INIT_TAIL) rq = after_init_tail();
         if (rq == GO_DIRECTION_TAIL) rq = direction_and_begin(refreshed);
         pending = rq;
+        if constexpr (PRIO >= 1) __builtin_amdgcn_s_setprio(0);
         return rq;
     }
     __device__ __forceinline__ double request_point() const { return ls.a_eval; }
