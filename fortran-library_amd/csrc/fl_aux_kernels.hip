@@ -222,7 +222,7 @@ int fl_lbfgs_two_loop_batched(int batch, int n, int memory, int recent, const do
                        hist_dev, rho_dev, g_dev, p_dev)
     if (nw == 1 && ept == 2) FL_TL(1, 2);
     else if (nw == 1 && ept == 4) FL_TL(1, 4);
-    else if (nw == 2 && ept == 4) FL_TL(2, 4);
+    else if (nw == 1 && ept == 8) FL_TL(1, 8);
     else if (nw == 4 && ept == 4) FL_TL(4, 4);
     else if (nw == 2 && ept == 8) FL_TL(2, 8);
     else if (nw == 8 && ept == 2) FL_TL(8, 2);

@@ -172,7 +172,7 @@ extern "C" {
         const int nw = threads / 64;                                                                              \
         if (nw == 1 && ept == 2) hipLaunchKernelGGL((fl::KERNEL<1, 2>), dim3(batch), dim3(64), 0, st, __VA_ARGS__); \
         else if (nw == 1 && ept == 4) hipLaunchKernelGGL((fl::KERNEL<1, 4>), dim3(batch), dim3(64), 0, st, __VA_ARGS__); \
-        else if (nw == 2 && ept == 4) hipLaunchKernelGGL((fl::KERNEL<2, 4>), dim3(batch), dim3(128), 0, st, __VA_ARGS__); \
+        else if (nw == 1 && ept == 8) hipLaunchKernelGGL((fl::KERNEL<1, 8>), dim3(batch), dim3(64), 0, st, __VA_ARGS__);  \
         else if (nw == 2 && ept == 8) hipLaunchKernelGGL((fl::KERNEL<2, 8>), dim3(batch), dim3(128), 0, st, __VA_ARGS__); \
         else if (nw == 4 && ept == 8) hipLaunchKernelGGL((fl::KERNEL<4, 8>), dim3(batch), dim3(256), 0, st, __VA_ARGS__); \
         else if (nw == 8 && ept == 8) hipLaunchKernelGGL((fl::KERNEL<8, 8>), dim3(batch), dim3(512), 0, st, __VA_ARGS__); \

@@ -398,7 +398,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
 #define FL_X0_LDS 1
 #endif
     static constexpr bool X0_LDS = FL_X0_LDS && (METHOD == FL_SOLVER_SD || METHOD == FL_SOLVER_CG) && !AUG &&
-                                   OBJ == FL_OBJ_DIAGQUAD && EPT == 8;
+                                   OBJ == FL_OBJ_DIAGQUAD && EPT == 8 && NW >= 2; // (one wave per problem: 44 spills under the cap)
     static constexpr int L_X0 = L_DEF + 2 * BF_DEFER;
     static constexpr int LDS_TOTAL = L_X0 + (X0_LDS ? NPAD : 0);
     using DN = Dense<NW, EPT>;

@@ -350,7 +350,7 @@ static int rci_step_any(fl_rci *h, double *x_dev, const double *f_dev, const dou
     if (nw == 16) fl::launch_rci_big(r, f_dev, g_dev, request_dev);
     else if (nw == 1 && ept == 2) fl::launch_rci<1, 2>(r, f_dev, g_dev, c_dev, cd_dev, request_dev);
     else if (nw == 1 && ept == 4) fl::launch_rci<1, 4>(r, f_dev, g_dev, c_dev, cd_dev, request_dev);
-    else if (nw == 2 && ept == 4) fl::launch_rci<2, 4>(r, f_dev, g_dev, c_dev, cd_dev, request_dev);
+    else if (nw == 1 && ept == 8) fl::launch_rci<1, 8>(r, f_dev, g_dev, c_dev, cd_dev, request_dev);
     else if (nw == 2 && ept == 8) fl::launch_rci<2, 8>(r, f_dev, g_dev, c_dev, cd_dev, request_dev);
     else if (nw == 4 && ept == 8) fl::launch_rci<4, 8>(r, f_dev, g_dev, c_dev, cd_dev, request_dev);
     else fl::launch_rci<8, 8>(r, f_dev, g_dev, c_dev, cd_dev, request_dev);

@@ -28,7 +28,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> constexpr int min_waves
     // (the quartic / Rosenbrock instances would spill 10-14 VGPRs under the cap: left alone)
     if (AUG && EPT == 4 && NW <= 2 && OBJ == FL_OBJ_DIAGQUAD && (METHOD == FL_SOLVER_LBFGS || METHOD == FL_SOLVER_CG)) return 4;
     // SD / CG on them at 8 elements per thread, x0 in LDS (Solver::X0_LDS)
-    if (!AUG && OBJ == FL_OBJ_DIAGQUAD && EPT == 8 && (METHOD == FL_SOLVER_SD || METHOD == FL_SOLVER_CG) && FL_X0_LDS) return 4;
+    if (!AUG && OBJ == FL_OBJ_DIAGQUAD && EPT == 8 && NW >= 2 && (METHOD == FL_SOLVER_SD || METHOD == FL_SOLVER_CG) && FL_X0_LDS) return 4;
     // L-BFGS on them at 4 elements per thread (n <= 512): 134-135
     if (!AUG && OBJ == FL_OBJ_DIAGQUAD && EPT == 4 && METHOD == FL_SOLVER_LBFGS) return 4;
     return 1;
@@ -127,9 +127,16 @@ static bool select_big_geometry(int n, GeoSel &g)
 static bool select_geometry(int n, GeoSel &g)
 {
     if (n <= 0) return false;
+#ifdef FL_FORCE_GEO_N // tuning builds: the bench geometry for FL_FORCE_GEO_LO < n <= FL_FORCE_GEO_N
+    if (n > FL_FORCE_GEO_LO && n <= FL_FORCE_GEO_N) {
+        g = {FL_BENCH_NW, FL_BENCH_EPT};
+        return true;
+    }
+#endif
     if (n <= 128) g = {1, 2};
     else if (n <= 256) g = {1, 4};
-    else if (n <= 512) g = {2, 4};
+    else if (n <= 512) g = {1, 8}; // one wave per problem: no cross-wave step in any reduction, and the reduction / line-search
+                                   // scalar work is done once instead of twice (2x4: 73.1, 1x8: 85.7 M it/s; profiles/r02/ab_geo.txt)
 #ifdef FL_BENCH_NW
     else if (n <= 1024) g = {FL_BENCH_NW, FL_BENCH_EPT};
 #endif
@@ -188,7 +195,7 @@ static hipError_t launch(const GeoSel &g, int obj, int method, int aug, const So
 #else
     if (g.nw == 1 && g.ept == 2) return launch_o<1, 2>(obj, method, aug, A, st);
     if (g.nw == 1 && g.ept == 4) return launch_o<1, 4>(obj, method, aug, A, st);
-    if (g.nw == 2 && g.ept == 4) return launch_o<2, 4>(obj, method, aug, A, st);
+    if (g.nw == 1 && g.ept == 8) return launch_o<1, 8>(obj, method, aug, A, st);
     if (g.nw == 2 && g.ept == 8) return launch_o<2, 8>(obj, method, aug, A, st);
     if (g.nw == 4 && g.ept == 8) return launch_o<4, 8>(obj, method, aug, A, st);
     return launch_o<8, 8>(obj, method, aug, A, st);
@@ -372,7 +379,7 @@ int fl_lbfgs_onchip_pairs(int objective, int n)
     if (!fl::select_geometry(n, g)) return 0; // vectors-in-HBM path: nothing of the ring stays on the chip
     if (g.nw == 1 && g.ept == 2) return fl::onchip_pairs_o<1, 2>(objective);
     if (g.nw == 1 && g.ept == 4) return fl::onchip_pairs_o<1, 4>(objective);
-    if (g.nw == 2 && g.ept == 4) return fl::onchip_pairs_o<2, 4>(objective);
+    if (g.nw == 1 && g.ept == 8) return fl::onchip_pairs_o<1, 8>(objective);
     if (g.nw == 2 && g.ept == 8) return fl::onchip_pairs_o<2, 8>(objective);
     if (g.nw == 4 && g.ept == 8) return fl::onchip_pairs_o<4, 8>(objective);
     return fl::onchip_pairs_o<8, 8>(objective);

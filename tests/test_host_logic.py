@@ -49,7 +49,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     lib.general_mp_dscientificnotation_(C.byref(xv), C.byref(iv))
     assert iv.value == -4 and abs(xv.value - 4.2) < 1e-12
     t, e = C.c_int(), C.c_int()
-    for n, (T, E) in {10: (64, 2), 256: (64, 4), 512: (128, 4), 1024: (128, 8), 2048: (256, 8), 4096: (512, 8)}.items():
+    for n, (T, E) in {10: (64, 2), 256: (64, 4), 512: (64, 8), 1024: (128, 8), 2048: (256, 8), 4096: (512, 8)}.items():
         assert lib.fl_reduction_geometry(n, C.byref(t), C.byref(e)) == 0 and (t.value, e.value) == (T, E)
     # beyond the register path: 1024 threads, 2*ceil(ceil(n/2)/1024) slots per thread (csrc/fl_big.hpp)
     assert lib.fl_reduction_geometry(100000, C.byref(t), C.byref(e)) == 0 and (t.value, e.value) == (1024, 98)

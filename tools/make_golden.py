@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as O
 
 GOLD = os.path.join(ROOT, "tests", "golden")
-GEO = {10: (64, 2), 96: (64, 2), 256: (64, 4), 512: (128, 4), 1024: (128, 8)}  # fl_reduction_geometry
+GEO = {10: (64, 2), 96: (64, 2), 256: (64, 4), 512: (64, 8), 1024: (128, 8)}  # fl_reduction_geometry
 
 
 def probes():
