@@ -112,6 +112,7 @@ def main():
            "iterations_per_launch": b["iterations_per_step"], "trials_per_launch": b["roofline"]["trial_phase"]["trials_per_launch"],
            "FETCH_SIZE_KiB_per_launch": cs["FETCH_SIZE"][0], "WRITE_SIZE_KiB_per_launch": cs["WRITE_SIZE"][0],
            "traffic_bytes_per_launch": (2 * cs["FETCH_SIZE"][0] + cs["WRITE_SIZE"][0]) * 1024,
+           "model_bytes_per_launch": b["roofline"]["model_bytes_per_launch"],
            "source": sorted(src)}
     for c in ("SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY",
               "SQ_WAIT_INST_ANY", "SQ_WAVES", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR",
