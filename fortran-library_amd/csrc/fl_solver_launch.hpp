@@ -1,0 +1,104 @@
+// fl_solver_launch.hpp -- the fused solver kernel (fl_solve_kernel) and its launchers by objective / solver for ONE
+// geometry <waves, elements per thread>.  Every geometry is instantiated in a translation unit of its own
+// (fl_solver_g*.hip: `template hipError_t fl::launch_o<NW, EPT>(...)`), so that the six of them compile in parallel
+// (one unit for all took six minutes); fl_solver_kernels.hip holds the dispatch by n and the C ABI.
+#pragma once
+#include "fl_device.hpp"
+#include "fl_host.hpp"
+
+namespace fl {
+
+// occupancy the register allocator is held to (waves per SIMD).  The augmented-Lagrangian L-BFGS / CG kernels at 4
+// elements per thread are bound by the latency of their ~45 objective-only trials per gradient (C5): 130 VGPRs gave
+// 3 waves, capped at 128 they run 4.
+template <int NW, int EPT, int OBJ, int METHOD, int AUG> constexpr int min_waves_per_simd()
+{
+#ifdef FL_MIN_WPE
+    return FL_MIN_WPE;
+#else
+    // (the quartic / Rosenbrock instances would spill 10-14 VGPRs under the cap: left alone)
+    if (AUG && EPT == 4 && NW <= 2 && OBJ == FL_OBJ_DIAGQUAD && (METHOD == FL_SOLVER_LBFGS || METHOD == FL_SOLVER_CG)) return 4;
+    // SD / CG on them at 8 elements per thread, x0 in LDS (Solver::X0_LDS)
+    if (!AUG && OBJ == FL_OBJ_DIAGQUAD && EPT == 8 && NW >= 2 && (METHOD == FL_SOLVER_SD || METHOD == FL_SOLVER_CG) && FL_X0_LDS) return 4;
+    // L-BFGS on them at 4 elements per thread (n <= 512): 134-135
+    if (!AUG && OBJ == FL_OBJ_DIAGQUAD && EPT == 4 && METHOD == FL_SOLVER_LBFGS) return 4;
+    return 1;
+#endif
+}
+
+template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = 0>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(min_waves_per_simd<NW, EPT, OBJ, METHOD, AUG>())))
+void fl_solve_kernel(SolveArgs A)
+{
+    using S = Solver<NW, EPT, OBJ, METHOD, AUG, EXACT>;
+#ifndef FL_LDS_PAD // tuning knob: extra LDS per workgroup caps the workgroups resident per CU
+#define FL_LDS_PAD 0
+#endif
+    __shared__ __attribute__((aligned(16))) double lds[S::LDS_TOTAL + FL_LDS_PAD];
+    S s(A, lds);
+    s.init();
+    int rq = s.start();
+    double fv = 0.0, pv = 0.0, gg = 0.0;
+    bool have_g = false; // augmented Lagrangian: objective-only trials skip the gradient until it is asked for
+    while (rq) {
+        // which evaluation the request needs (each form is inlined once)
+        bool f_only = false, full = false;
+        if (!(rq & FL_REQ_SAME)) {
+            if (!(rq & FL_REQ_NOMOVE)) s.move(s.request_point());
+            if (AUG && !(rq & FL_REQ_G)) f_only = true;
+            else full = true;
+        } else if (AUG && (rq & FL_REQ_G) && !have_g) { // gradient at the point whose objective is already known
+            full = true;
+        }
+        if (AUG && f_only) {
+            s.template evaluate<false>(fv, pv, gg);
+            have_g = false;
+        }
+        if (full) {
+            s.template evaluate<true>(fv, pv, gg);
+            have_g = true;
+        }
+        rq = s.advance(fv, pv, gg);
+    }
+    s.finish();
+}
+
+template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = 0>
+static hipError_t launch_k(const SolveArgs &A, hipStream_t st)
+{
+    hipLaunchKernelGGL((fl_solve_kernel<NW, EPT, OBJ, METHOD, AUG, EXACT>), dim3(A.batch), dim3(NW * 64), 0, st, A);
+    return hipGetLastError();
+}
+template <int NW, int EPT, int OBJ> static hipError_t launch_m(int method, int aug, const SolveArgs &A, hipStream_t st)
+{
+    if (aug) { // augmented Lagrangian around L-BFGS, CG (NO.f90:2150-2185) or quasi-Newton BFGS (2131-2148, ExactStep <= 0)
+        if (method == FL_SOLVER_CG) return launch_k<NW, EPT, OBJ, FL_SOLVER_CG, 1>(A, st);
+        // NewtonRaphson / exact-Hessian BFGS around the Hessian of L (Ldd): up to n = 2048 (solve() refuses beyond: at 512
+        // threads the Cholesky kernels, the deferred updates and the constraint terms together do not fit 256 VGPRs)
+        if constexpr (NW < 8) {
+            if (method == FL_SOLVER_NEWTON) return launch_k<NW, EPT, OBJ, FL_SOLVER_NEWTON, 1>(A, st); // fdd=Ldd (2074-2130)
+            if (method == FL_SOLVER_BFGS && A.exact_step > 0) return launch_k<NW, EPT, OBJ, FL_SOLVER_BFGS, 1, 1>(A, st);
+        }
+        if (method == FL_SOLVER_BFGS) return launch_k<NW, EPT, OBJ, FL_SOLVER_BFGS, 1, 0>(A, st);
+        return launch_k<NW, EPT, OBJ, FL_SOLVER_LBFGS, 1>(A, st);
+    }
+    switch (method) {
+    case FL_SOLVER_SD: return launch_k<NW, EPT, OBJ, FL_SOLVER_SD, 0>(A, st);
+    case FL_SOLVER_CG: return launch_k<NW, EPT, OBJ, FL_SOLVER_CG, 0>(A, st);
+    case FL_SOLVER_BFGS: // the exact-Hessian refresh (Cholesky kernels) is compiled into its own instantiation
+        if (A.exact_step > 0) return launch_k<NW, EPT, OBJ, FL_SOLVER_BFGS, 0, 1>(A, st);
+        return launch_k<NW, EPT, OBJ, FL_SOLVER_BFGS, 0, 0>(A, st);
+    case FL_SOLVER_NEWTON: return launch_k<NW, EPT, OBJ, FL_SOLVER_NEWTON, 0>(A, st);
+    default: return launch_k<NW, EPT, OBJ, FL_SOLVER_LBFGS, 0>(A, st);
+    }
+}
+template <int NW, int EPT> hipError_t launch_o(int obj, int method, int aug, const SolveArgs &A, hipStream_t st)
+{
+    switch (obj) {
+    case FL_OBJ_QUARTIC: return launch_m<NW, EPT, FL_OBJ_QUARTIC>(method, aug, A, st);
+    case FL_OBJ_ROSENBROCK: return launch_m<NW, EPT, FL_OBJ_ROSENBROCK>(method, aug, A, st);
+    default: return launch_m<NW, EPT, FL_OBJ_DIAGQUAD>(method, aug, A, st);
+    }
+}
+
+} // namespace fl
