@@ -31,6 +31,7 @@ FL.fl_version.restype = C.c_int
 FL.fl_default_options.argtypes = [C.POINTER(Options), C.c_int]
 FL.fl_default_options.restype = None
 FL.fl_reduction_geometry.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+FL.fl_reduction_geometry_for.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
 FL.fl_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
 FL.fl_workspace_bytes.restype = C.c_size_t
 FL.fl_lbfgs_batched.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.POINTER(Options), _vp, C.c_size_t, _dp,
@@ -82,9 +83,14 @@ def default_options(solver, **kw):
     return o
 
 
-def reduction_geometry(n):
+def reduction_geometry(n, solver=None):
+    """(threads, elements per thread) of the kernels' fixed summation order for dimension n; with `solver` (SD | CG |
+    LBFGS_ | BFGS_ | 4): of that solver's fused kernel (fl_reduction_geometry_for)"""
     t, e = C.c_int(), C.c_int()
-    _check(FL.fl_reduction_geometry(n, C.byref(t), C.byref(e)), "fl_reduction_geometry")
+    if solver is None:
+        _check(FL.fl_reduction_geometry(n, C.byref(t), C.byref(e)), "fl_reduction_geometry")
+    else:
+        _check(FL.fl_reduction_geometry_for(int(solver), n, C.byref(t), C.byref(e)), "fl_reduction_geometry_for")
     return t.value, e.value
 
 

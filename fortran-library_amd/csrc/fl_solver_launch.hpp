@@ -101,4 +101,19 @@ template <int NW, int EPT> hipError_t launch_o(int obj, int method, int aug, con
     }
 }
 
+// SD / CG without constraints only: the geometries that exist for them alone (fl_solver_g116.hip)
+template <int NW, int EPT, int OBJ> static hipError_t launch_vec_m(int method, const SolveArgs &A, hipStream_t st)
+{
+    if (method == FL_SOLVER_SD) return launch_k<NW, EPT, OBJ, FL_SOLVER_SD, 0>(A, st);
+    return launch_k<NW, EPT, OBJ, FL_SOLVER_CG, 0>(A, st);
+}
+template <int NW, int EPT> hipError_t launch_vec(int obj, int method, const SolveArgs &A, hipStream_t st)
+{
+    switch (obj) {
+    case FL_OBJ_QUARTIC: return launch_vec_m<NW, EPT, FL_OBJ_QUARTIC>(method, A, st);
+    case FL_OBJ_ROSENBROCK: return launch_vec_m<NW, EPT, FL_OBJ_ROSENBROCK>(method, A, st);
+    default: return launch_vec_m<NW, EPT, FL_OBJ_DIAGQUAD>(method, A, st);
+    }
+}
+
 } // namespace fl

@@ -102,6 +102,11 @@ void fl_default_options(fl_options *opt, int solver);
  * ept = 2*ceil(ceil(n/2)/1024) (csrc/fl_big.hpp).
  * FL_ERR_UNSUPPORTED_SIZE beyond 2^27. */
 int fl_reduction_geometry(int n, int *threads, int *ept);
+/* The geometry of the FUSED kernel of one solver (fl_*_batched without constraints): as above except that
+ * FL_SOLVER_SD / FL_SOLVER_CG run 512 < n <= 1024 with one wave x 16 elements per thread (no history to keep: the
+ * state fits one wave).  threads*ept -- the padded length of every workspace row -- is the same for all solvers of
+ * an n; the reverse-communication kernels (fl_rci_*) and the dense routines use fl_reduction_geometry's. */
+int fl_reduction_geometry_for(int solver, int n, int *threads, int *ept);
 
 /* The fused L-BFGS kernel keeps the newest pairs of its (s, y) ring on the chip (registers, then an LDS ring); this
  * returns how many for a built-in objective and dimension n (0 beyond n = 4096).  With C of them on the chip an

@@ -53,7 +53,7 @@ def _oracle_opts(solver, kw):
 def _both(solver, kind, x0, d=None, b=None, mode=O.TREE, **kw):
     NLO = _nlo()
     n = np.atleast_2d(x0).shape[1]
-    T, E = NLO.reduction_geometry(n)
+    T, E = NLO.reduction_geometry(n, solver)  # (the fused SD / CG kernels have a geometry of their own for 512 < n <= 1024)
     g = _gpu_solve(solver, kind, x0, d, b, **kw)
     o = O.solve_batch(solver, kind, x0, d=d, b=b, opts=_oracle_opts(solver, kw), use_ffd=bool(kw.get("f_fd", False)),
                       sum_mode=mode, threads=T, ept=E)

@@ -48,10 +48,18 @@ def test_c_abi_library_exports_every_declared_symbol():
     xv = C.c_double(0.00042)
     lib.general_mp_dscientificnotation_(C.byref(xv), C.byref(iv))
     assert iv.value == -4 and abs(xv.value - 4.2) < 1e-12
-    t, e = C.c_int(), C.c_int()
+    t, e, t2, e2 = C.c_int(), C.c_int(), C.c_int(), C.c_int()
     for n, (T, E) in {10: (64, 2), 256: (64, 4), 512: (64, 8), 1024: (128, 8), 2048: (256, 8), 4096: (512, 8)}.items():
         assert lib.fl_reduction_geometry(n, C.byref(t), C.byref(e)) == 0 and (t.value, e.value) == (T, E)
     # beyond the register path: 1024 threads, 2*ceil(ceil(n/2)/1024) slots per thread (csrc/fl_big.hpp)
+    # the fused SD / CG kernels: one wave x 16 elements for 512 < n <= 1024, everything else as the layout geometry; the
+    # padded row length threads*ept never depends on the solver
+    for solver in range(5):
+        for n in (10, 256, 512, 513, 700, 1024, 1025, 4096, 5000):
+            assert lib.fl_reduction_geometry(n, C.byref(t), C.byref(e)) == 0
+            assert lib.fl_reduction_geometry_for(solver, n, C.byref(t2), C.byref(e2)) == 0
+            want = (64, 16) if solver in (0, 1) and 512 < n <= 1024 else (t.value, e.value)
+            assert (t2.value, e2.value) == want and t2.value * e2.value == t.value * e.value
     assert lib.fl_reduction_geometry(100000, C.byref(t), C.byref(e)) == 0 and (t.value, e.value) == (1024, 98)
     assert lib.fl_reduction_geometry(4097, C.byref(t), C.byref(e)) == 0 and (t.value, e.value) == (1024, 6)
     assert lib.fl_reduction_geometry((1 << 27) + 1, C.byref(t), C.byref(e)) == -2

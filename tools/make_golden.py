@@ -20,6 +20,7 @@ import oracle_lib as O
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 GEO = {10: (64, 2), 96: (64, 2), 256: (64, 4), 512: (64, 8), 1024: (128, 8)}  # fl_reduction_geometry
+GEO_CG_1024 = (64, 16)  # fl_reduction_geometry_for(FL_SOLVER_CG, 1024): the fused SD / CG kernels, 512 < n <= 1024
 
 
 def probes():
@@ -77,8 +78,8 @@ def vectors():
     kappa = np.exp(rng.uniform(np.log(10), np.log(1000), 4))
     d = 1.0 + (kappa[:, None] - 1.0) * (np.arange(n) / (n - 1))[None, :]
     b = rng.uniform(-1, 1, (4, n))
-    T, E = GEO[1024]
     for nm, solver, o in (("lbfgs", O.LBFGS, O.defaults(precision=1e-6)), ("cgdy", O.CG, O.defaults(c2=0.45, precision=1e-6))):
+        T, E = GEO_CG_1024 if solver == O.CG else GEO[1024]
         put(f"quad1024_{nm}", O.solve_batch(solver, O.DIAGQUAD, np.zeros((4, n)), d=d, b=b, opts=o, sum_mode=O.TREE,
                                             threads=T, ept=E), {"d": d, "b": b})
     # config 5 shape: augmented Lagrangian n=512, M=8
