@@ -361,7 +361,16 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
 #define FL_LDS_BUDGET 2560 // doubles of LDS per wave: 20 KiB, what 2 waves / SIMD (8 waves per CU) leave each
 #endif
     static constexpr int LDS_PAIRS_FIT = (FL_LDS_BUDGET * NW - L_G0) / (2 * NPAD);
-    static constexpr int LDS_PAIRS_WANT = (METHOD == FL_SOLVER_LBFGS && OBJ != FL_OBJ_EXTERNAL) ? FL_LDS_PAIRS(NW, EPT) : 0;
+    // AUG_LEAN18: the augmented-Lagrangian L-BFGS / CG kernels of the one-wave geometry (256 < n <= 512, C5) are bound by the
+    // latency of their trial chain (~75 trials per inner iteration, one two-loop), not by ring traffic: they give up the
+    // on-chip pairs, the row prefetch of the recursion (direction_lbfgs_plain) and the register copy of x0 for a third
+    // wave per SIMD (208 -> <= 168 VGPRs).
+#ifndef FL_AUG_LEAN18
+#define FL_AUG_LEAN18 1
+#endif
+    static constexpr bool AUG_LEAN18 = FL_AUG_LEAN18 && AUG && NW == 1 && EPT == 8 && OBJ == FL_OBJ_DIAGQUAD &&
+                                       (METHOD == FL_SOLVER_LBFGS || METHOD == FL_SOLVER_CG);
+    static constexpr int LDS_PAIRS_WANT = (METHOD == FL_SOLVER_LBFGS && OBJ != FL_OBJ_EXTERNAL && !AUG_LEAN18) ? FL_LDS_PAIRS(NW, EPT) : 0;
     static constexpr int LDS_PAIRS = LDS_PAIRS_WANT < LDS_PAIRS_FIT ? LDS_PAIRS_WANT : LDS_PAIRS_FIT;
     static constexpr int L_BF = L_G0 + ((NEEDS_G0 && METHOD != FL_SOLVER_BFGS) ? (LDS_PAIRS > 0 ? 2 * LDS_PAIRS * NPAD : NPAD) : 0);
     // ... and the REG_PAIRS newest pairs stay in REGISTERS from one iteration to the next (the LDS ring then holds the
@@ -397,8 +406,8 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
 #ifndef FL_X0_LDS
 #define FL_X0_LDS 1
 #endif
-    static constexpr bool X0_LDS = FL_X0_LDS && (METHOD == FL_SOLVER_SD || METHOD == FL_SOLVER_CG) && !AUG &&
-                                   OBJ == FL_OBJ_DIAGQUAD && EPT == 8 && NW >= 2; // (one wave per problem: 44 spills under the cap)
+    static constexpr bool X0_LDS = AUG_LEAN18 || (FL_X0_LDS && (METHOD == FL_SOLVER_SD || METHOD == FL_SOLVER_CG) && !AUG &&
+                                   OBJ == FL_OBJ_DIAGQUAD && EPT == 8 && NW >= 2); // (one wave per problem: 44 spills under the cap)
     static constexpr int L_X0 = L_DEF + 2 * BF_DEFER;
     static constexpr int LDS_TOTAL = L_X0 + (X0_LDS ? NPAD : 0);
     using DN = Dense<NW, EPT>;
@@ -1165,8 +1174,82 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
         a = a * phidold / phid;
     }
 
+    // The recursion without any of the traffic machinery: the new pair goes to the ring, every pair is fetched where it
+    // is used, one row at a time.  Same arithmetic in the same order as direction_lbfgs (bit for bit).
+    __device__ __forceinline__ void direction_lbfgs_plain(const double (&g0)[EPT])
+    {
+        double *hist = hist_base();
+        double *rho_s = lds + L_RHO, *alpha_s = lds + L_ALPHA;
+        const int mem = A.mem;
+        recent = (recent + 1 == mem) ? 0 : recent + 1;
+        if (cnt < mem) ++cnt;
+        double r[2];
+        {
+            double sv[EPT], yv[EPT];
+            if constexpr (X0_LDS) load_pad<NW, EPT>(lds + L_X0, sv);
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+                sv[k] = x[k] - (X0_LDS ? sv[k] : x0[X0_LDS ? 0 : k]);
+                yv[k] = g[k] - g0[k];
+            }
+            store_pad<NW, EPT>(hist + (size_t)(2 * recent) * NPAD, sv);
+            store_pad<NW, EPT>(hist + (size_t)(2 * recent + 1) * NPAD, yv);
+            r[0] = dot_part<EPT>(yv, sv);
+            r[1] = dot_part<EPT>(yv, yv);
+        }
+        R.run(r);
+        if (threadIdx.x == 0) rho_s[recent] = 1.0 / r[0];
+        rho_recent = uni(1.0 / r[0]);
+        yy_recent = uni(r[1]);
+        __syncthreads(); // rho_s; and the ring rows just stored are read back by the threads that wrote them
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) p[k] = g[k];
+        auto slot_of = [&](int j) {
+            int s_ = recent - j;
+            return s_ < 0 ? s_ + mem : s_;
+        };
+        for (int j = 0; j < cnt; ++j) { // newest -> oldest
+            const int sl = slot_of(j);
+            double row[EPT];
+            load_pad<NW, EPT>(hist + (size_t)(2 * sl) * NPAD, row);
+            double q[1] = {dot_part<EPT>(row, p)};
+            R.run(q);
+            const double al = rho_s[sl] * q[0];
+            if (threadIdx.x == 0) alpha_s[sl] = al;
+            load_pad<NW, EPT>(hist + (size_t)(2 * sl + 1) * NPAD, row);
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) p[k] = p[k] - al * row[k];
+        }
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) p[k] = p[k] / rho_recent / yy_recent;
+        __syncthreads(); // alpha_s
+        for (int j = cnt - 1; j >= 0; --j) { // oldest -> newest
+            const int sl = slot_of(j);
+            double row[EPT];
+            load_pad<NW, EPT>(hist + (size_t)(2 * sl + 1) * NPAD, row);
+            double q[1] = {dot_part<EPT>(row, p)};
+            R.run(q);
+            const double be = rho_s[sl] * q[0];
+            const double co = alpha_s[sl] - be;
+            load_pad<NW, EPT>(hist + (size_t)(2 * sl) * NPAD, row);
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) p[k] = p[k] + co * row[k];
+        }
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) p[k] = -p[k];
+        r[0] = dot_part<EPT>(g, p);
+        r[1] = dot_part<EPT>(p, p);
+        R.run(r);
+        phid = r[0];
+        pp = r[1];
+        a = 1.0;
+    }
     __device__ __forceinline__ void direction_lbfgs(const double (&g0)[EPT])
     {
+        if constexpr (AUG_LEAN18) {
+            direction_lbfgs_plain(g0);
+            return;
+        }
         double *hist = hist_base();
         double *rho_s = lds + L_RHO, *alpha_s = lds + L_ALPHA;
         const int mem = A.mem;

@@ -18,6 +18,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> constexpr int min_waves
 #else
     // (the quartic / Rosenbrock instances would spill 10-14 VGPRs under the cap: left alone)
     if (AUG && EPT == 4 && NW <= 2 && OBJ == FL_OBJ_DIAGQUAD && (METHOD == FL_SOLVER_LBFGS || METHOD == FL_SOLVER_CG)) return 4;
+    if (FL_AUG_LEAN18 && AUG && EPT == 8 && NW == 1 && OBJ == FL_OBJ_DIAGQUAD && (METHOD == FL_SOLVER_LBFGS || METHOD == FL_SOLVER_CG)) return 3; // Solver::AUG_LEAN18 (4 waves: 80-100 spills)
     // SD / CG on them at 8 elements per thread, x0 in LDS (Solver::X0_LDS)
     if (!AUG && OBJ == FL_OBJ_DIAGQUAD && EPT == 8 && NW >= 2 && (METHOD == FL_SOLVER_SD || METHOD == FL_SOLVER_CG) && FL_X0_LDS) return 4;
     // L-BFGS on them at 4 elements per thread (n <= 512): 134-135
