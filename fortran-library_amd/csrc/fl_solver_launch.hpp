@@ -117,4 +117,17 @@ template <int NW, int EPT> hipError_t launch_vec(int obj, int method, const Solv
     }
 }
 
+// NewtonRaphson only (with or without the augmented Lagrangian around it): fl_solver_g24.hip
+template <int NW, int EPT> hipError_t launch_newton(int obj, int aug, const SolveArgs &A, hipStream_t st)
+{
+#define FL_NEWTON(O_)                                                                      \
+    return aug ? launch_k<NW, EPT, O_, FL_SOLVER_NEWTON, 1>(A, st) : launch_k<NW, EPT, O_, FL_SOLVER_NEWTON, 0>(A, st)
+    switch (obj) {
+    case FL_OBJ_QUARTIC: FL_NEWTON(FL_OBJ_QUARTIC);
+    case FL_OBJ_ROSENBROCK: FL_NEWTON(FL_OBJ_ROSENBROCK);
+    default: FL_NEWTON(FL_OBJ_DIAGQUAD);
+    }
+#undef FL_NEWTON
+}
+
 } // namespace fl

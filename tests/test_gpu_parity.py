@@ -345,7 +345,7 @@ def test_bfgs_exact_hessian_refresh_bitexact(kind, n, kw):
 
 @pytest.mark.parametrize("kind,n,kw", [(O.ROSENBROCK, 10, {}), (O.ROSENBROCK, 10, {"f_fd": True}), (O.ROSENBROCK, 10, {"Strong": False}),
                                        (O.QUARTIC, 10, {}), (O.DIAGQUAD, 96, {}), (O.ROSENBROCK, 130, {}),
-                                       (O.ROSENBROCK, 257, {"MaxIteration": 8}), (O.DIAGQUAD, 600, {})])
+                                       (O.ROSENBROCK, 257, {"MaxIteration": 8}), (O.DIAGQUAD, 400, {}), (O.DIAGQUAD, 600, {})])
 def test_newton_raphson_bitexact(kind, n, kw):
     """NewtonRaphson with analytic Hessian (NO.f90:1026-1271): Cholesky solve (My_dposv) per iteration,
     steepest-descent fallback where the Hessian is not positive definite (Rosenbrock's standard start)."""
@@ -370,7 +370,7 @@ def test_newton_raphson_bitexact(kind, n, kw):
     torch.cuda.synchronize()
     g = {k: v.cpu().numpy() for k, v in out.items() if k != "workspace"}
     g["x"] = x.cpu().numpy()
-    T, E = NLO.reduction_geometry(n)
+    T, E = NLO.reduction_geometry(n, 4)
     o = O.solve_batch(4, kind, x0, d=d, b=b, opts=_oracle_opts(4, kw), use_ffd=bool(kw.get("f_fd", False)),
                       sum_mode=O.TREE, threads=T, ept=E)
     _assert_bitexact(g, o)
@@ -644,7 +644,7 @@ def test_augmented_lagrangian_with_the_hessian_of_L_bitexact(solver_name, solver
     if kind == O.DIAGQUAD:
         d, b = _quads(B, n, 2.0, 10.0, 5)
     g = _gpu_auglag(solver_name, kind, x0, m, d, b, **kw)
-    T, E = NLO.reduction_geometry(n)
+    T, E = NLO.reduction_geometry(n, 4 if solver == 4 else None)
     oo = _oracle_opts(O.BFGS if solver == O.BFGS else O.LBFGS, kw)
     oo.exact_step = int(kw.get("ExactStep", 0))
     O.lib().flo_set_auglag_bfgs_form(1)
