@@ -98,7 +98,7 @@ static bool select_geometry(int n, GeoSel &g)
 static bool select_fused_geometry(int n, int method, bool aug, GeoSel &g)
 {
     if (!select_geometry(n, g)) return false;
-    if (!aug && (method == FL_SOLVER_SD || method == FL_SOLVER_CG) && n > 512 && n <= 1024) g = {1, 16};
+    if (!aug && (method == FL_SOLVER_SD || method == FL_SOLVER_CG) && n > 512) g = {g.nw / 2, 16}; // 1 x 16, 2 x 16, 4 x 16
     // NewtonRaphson (also inside the augmented Lagrangian) keeps two waves x 4 for 256 < n <= 512: the Cholesky kernels of
     // one workgroup run 17 % faster on 128 threads than on 64 (profiles/r02/ab_geo.txt)
     if (method == FL_SOLVER_NEWTON && n > 256 && n <= 512) g = {2, 4};
@@ -107,6 +107,8 @@ static bool select_fused_geometry(int n, int method, bool aug, GeoSel &g)
 
 #ifndef FL_ONLY_BENCH // the geometries are compiled in fl_solver_g*.hip
 extern template hipError_t launch_vec<1, 16>(int, int, const SolveArgs &, hipStream_t);
+extern template hipError_t launch_vec<2, 16>(int, int, const SolveArgs &, hipStream_t);
+extern template hipError_t launch_vec<4, 16>(int, int, const SolveArgs &, hipStream_t);
 extern template hipError_t launch_newton<2, 4>(int, int, const SolveArgs &, hipStream_t);
 extern template hipError_t launch_o<1, 2>(int, int, int, const SolveArgs &, hipStream_t);
 extern template hipError_t launch_o<1, 4>(int, int, int, const SolveArgs &, hipStream_t);
@@ -125,6 +127,8 @@ static hipError_t launch(const GeoSel &g, int obj, int method, int aug, const So
     return launch_k<FL_BENCH_NW, FL_BENCH_EPT, FL_OBJ_DIAGQUAD, FL_SOLVER_LBFGS, 0>(A, st);
 #else
     if (g.nw == 1 && g.ept == 16) return launch_vec<1, 16>(obj, method, A, st); // (select_fused_geometry: SD / CG, no constraints)
+    if (g.nw == 2 && g.ept == 16) return launch_vec<2, 16>(obj, method, A, st);
+    if (g.nw == 4 && g.ept == 16) return launch_vec<4, 16>(obj, method, A, st);
     if (g.nw == 2 && g.ept == 4) return launch_newton<2, 4>(obj, aug, A, st);      // (select_fused_geometry: NewtonRaphson)
     if (g.nw == 1 && g.ept == 2) return launch_o<1, 2>(obj, method, aug, A, st);
     if (g.nw == 1 && g.ept == 4) return launch_o<1, 4>(obj, method, aug, A, st);

@@ -103,8 +103,8 @@ void fl_default_options(fl_options *opt, int solver);
  * FL_ERR_UNSUPPORTED_SIZE beyond 2^27. */
 int fl_reduction_geometry(int n, int *threads, int *ept);
 /* The geometry of the FUSED kernel of one solver (fl_*_batched without constraints): as above except that
- * FL_SOLVER_SD / FL_SOLVER_CG run 512 < n <= 1024 with one wave x 16 elements per thread (no history to keep: the
- * state fits one wave) and FL_SOLVER_NEWTON 256 < n <= 512 with two waves x 4 (its Cholesky wants the threads).  threads*ept -- the padded length of every workspace row -- is the same for all solvers of
+ * FL_SOLVER_SD / FL_SOLVER_CG run 512 < n <= 4096 with 16 elements per thread and half the waves (1 / 2 / 4 x 16: no
+ * history to keep, the state fits) and FL_SOLVER_NEWTON 256 < n <= 512 with two waves x 4 (its Cholesky wants the threads).  threads*ept -- the padded length of every workspace row -- is the same for all solvers of
  * an n; the reverse-communication kernels (fl_rci_*) and the dense routines use fl_reduction_geometry's. */
 int fl_reduction_geometry_for(int solver, int n, int *threads, int *ept);
 

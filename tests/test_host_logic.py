@@ -55,10 +55,10 @@ def test_c_abi_library_exports_every_declared_symbol():
     # the fused SD / CG kernels: one wave x 16 elements for 512 < n <= 1024, everything else as the layout geometry; the
     # padded row length threads*ept never depends on the solver
     for solver in range(5):
-        for n in (10, 256, 257, 400, 512, 513, 700, 1024, 1025, 4096, 5000):
+        for n in (10, 256, 257, 400, 512, 513, 700, 1024, 1025, 2048, 2049, 4096, 5000):
             assert lib.fl_reduction_geometry(n, C.byref(t), C.byref(e)) == 0
             assert lib.fl_reduction_geometry_for(solver, n, C.byref(t2), C.byref(e2)) == 0
-            want = (64, 16) if solver in (0, 1) and 512 < n <= 1024 else ((128, 4) if solver == 4 and 256 < n <= 512 else (t.value, e.value))
+            want = (t.value // 2, 16) if solver in (0, 1) and 512 < n <= 4096 else ((128, 4) if solver == 4 and 256 < n <= 512 else (t.value, e.value))
             assert (t2.value, e2.value) == want and t2.value * e2.value == t.value * e.value
     assert lib.fl_reduction_geometry(100000, C.byref(t), C.byref(e)) == 0 and (t.value, e.value) == (1024, 98)
     assert lib.fl_reduction_geometry(4097, C.byref(t), C.byref(e)) == 0 and (t.value, e.value) == (1024, 6)
