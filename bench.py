@@ -59,7 +59,7 @@ def kernel_source_hash():
     """identifies the kernel a PMC record was taken from: the sources the fused solver kernel is compiled from"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("fl_device.hpp", "fl_reduce.hpp", "fl_linesearch.hpp", "fl_dense.hpp", "fl_solver_launch.hpp", "fl_solver_kernels.hip"):
+    for f in ("fl_device.hpp", "fl_reduce.hpp", "fl_linesearch.hpp", "fl_dense.hpp", "fl_solver_launch.hpp"):  # (device code only)
         h.update(open(os.path.join(ROOT, "fortran-library_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
