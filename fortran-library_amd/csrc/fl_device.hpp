@@ -100,22 +100,48 @@ template <int NW, int EPT> __device__ __forceinline__ void store_user(double *ro
     }
 }
 // padded rows (NPAD doubles, 16-byte aligned): HBM workspaces and LDS parking
+// FL_SADDR (geometries of at most FL_SADDR waves): the row pointer is workgroup-uniform, so the address is written as
+// (uniform base) + (32-bit byte offset of the thread) + (chunk offset, a constant) -- the form the `global_load ... v_off,
+// s[base]` addressing takes with ONE kept offset register and no vector arithmetic per load; the laundered index of
+// Geo::tid() costs four vector instructions per load (32 per two-loop step of the headline kernel).
+#ifndef FL_SADDR
+#define FL_SADDR 2
+#endif
 template <int NW, int EPT> __device__ __forceinline__ void load_pad(const double *row, double (&v)[EPT])
 {
     using G = Geo<NW, EPT>;
+    if constexpr (NW <= FL_SADDR) {
+        const unsigned off = threadIdx.x * 16u;
+        const char *base = reinterpret_cast<const char *>(row);
 #pragma unroll
-    for (int c = 0; c < G::NCH; ++c) {
-        const double2 t = *reinterpret_cast<const double2 *>(row + G::e0(c));
-        v[2 * c] = t.x;
-        v[2 * c + 1] = t.y;
+        for (int c = 0; c < G::NCH; ++c) {
+            const double2 t = *reinterpret_cast<const double2 *>(base + (off + (unsigned)(c * G::T * 16)));
+            v[2 * c] = t.x;
+            v[2 * c + 1] = t.y;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < G::NCH; ++c) {
+            const double2 t = *reinterpret_cast<const double2 *>(row + G::e0(c));
+            v[2 * c] = t.x;
+            v[2 * c + 1] = t.y;
+        }
     }
 }
 template <int NW, int EPT> __device__ __forceinline__ void store_pad(double *row, const double (&v)[EPT])
 {
     using G = Geo<NW, EPT>;
+    if constexpr (NW <= FL_SADDR) {
+        const unsigned off = threadIdx.x * 16u;
+        char *base = reinterpret_cast<char *>(row);
 #pragma unroll
-    for (int c = 0; c < G::NCH; ++c)
-        *reinterpret_cast<double2 *>(row + G::e0(c)) = make_double2(v[2 * c], v[2 * c + 1]);
+        for (int c = 0; c < G::NCH; ++c)
+            *reinterpret_cast<double2 *>(base + (off + (unsigned)(c * G::T * 16))) = make_double2(v[2 * c], v[2 * c + 1]);
+    } else {
+#pragma unroll
+        for (int c = 0; c < G::NCH; ++c)
+            *reinterpret_cast<double2 *>(row + G::e0(c)) = make_double2(v[2 * c], v[2 * c + 1]);
+    }
 }
 
 template <int EPT> __device__ __forceinline__ double dot_part(const double (&a)[EPT], const double (&b)[EPT])
