@@ -361,7 +361,26 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
     // scratch of the Cholesky kernels (pivot and multipliers of a block: 2 + BW doubles).  Its own slot: with the
     // augmented Lagrangian around NewtonRaphson / exact BFGS, c(x) must survive the factorisation (inner_finished reads
     // it when the inner solver stops on MaxIteration right after a direction)
-    static constexpr int L_SLOT = L_CX + 2 * FL_MAX_CONSTRAINTS; // (c(x) is double buffered: cx_ptr())
+    // SPEC_K > 1: the objective-only shrink / grow loops of the line searchers (StrongWolfe NO.f90:1517-1521 and its
+    // _fdwithf twin 1636-1640; Wolfe 1308-1313, 1325-1329) walk a_k = a_{k-1} / incrmt (or * incrmt) and only their EXIT
+    // depends on the objective values.  The fused augmented-Lagrangian kernels run such a loop as a tight loop of their
+    // own (fast_forward) instead of one pass through the whole machine per trial: SPEC_K consecutive step lengths are
+    // evaluated per pass -- SPEC_K independent arithmetic chains, the reductions of all of them sharing one tree pass
+    // (fl_reduce.hpp: four values cost little more than one) -- the exit test of the reference is applied to them in
+    // order, what lies behind the first exit is discarded, and the machine is handed the exit trial with the state it
+    // would have reached by itself.  Every value has the bits of a trial evaluated on its own, and nf counts what the
+    // reference would have called.  C5 (45 objective-only trials per gradient, one wave per problem, a tail of long
+    // problems on a mostly idle chip): profiles/r03/c5_spec_ab.txt.
+#ifndef FL_SPEC_K
+#define FL_SPEC_K 4
+#endif
+#ifndef FL_SPEC_X0_RELOAD
+#define FL_SPEC_X0_RELOAD 1
+#endif
+    static constexpr int SPEC_K = (AUG && (OBJ == FL_OBJ_DIAGQUAD || OBJ == FL_OBJ_QUARTIC) && NW < 8 && FL_SPEC_K > 1) ? FL_SPEC_K : 1;
+    static_assert(SPEC_K == 1 || SPEC_K == 2 || SPEC_K == 4, "1, 2 or 4 speculative trials");
+    static constexpr int L_CXS = L_CX + 2 * FL_MAX_CONSTRAINTS;  // c(x) of the speculative trials [2][SPEC_K][FL_MAX_CONSTRAINTS]
+    static constexpr int L_SLOT = L_CXS + (SPEC_K > 1 ? 2 * SPEC_K * FL_MAX_CONSTRAINTS : 0); // (c(x) is double buffered: cx_ptr())
     static constexpr int L_XS = (L_SLOT + 16 + 1) & ~1;
     static constexpr int L_G0 = (L_XS + (Obj::LDS_DOUBLES > 0 ? Obj::LDS_DOUBLES : 0) + 1) & ~1;
     // BFGS: s, q, g broadcast arrays; the first one doubles as the g_old parking slot (the
@@ -462,6 +481,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
     int outer_it, inner_iters_total;
     int blk[AUG ? EPT : 1]; // constraint block of each of the thread's elements (-1 = padding)
     int cpar;               // which of the two c(x) buffers holds the last evaluation's constraints
+    int spar;               // ... and which half of the speculative trials' buffers the last batch wrote
     int cshift;             // log2 of the lanes per constraint block where blocks are aligned lane groups (4, 5, 6), else 0
 
     enum { PH_INIT = 0, PH_LS = 1, PH_DONE = 2, PH_HESS = 3 };
@@ -583,6 +603,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
         miu = 0.0;
         cshift = 0;
         cpar = 0;
+        spar = 0;
         if constexpr (AUG) {
             if constexpr (OBJ != FL_OBJ_EXTERNAL) { // the built-in constraint family: block spheres
                 const int w = n / A.aug_m;
@@ -746,6 +767,158 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
         double q[1] = {dot_part<EPT>(g, g)};
         R.run(q);
         return uni(q[0]);
+    }
+
+    // ---------------------------------------------------------------- speculative objective-only trials (SPEC_K)
+    // +1: the pending objective-only request opens (or continues) a loop a <- a * incrmt, -1: a <- a / incrmt, 0: neither
+    __device__ __forceinline__ int spec_direction() const
+    {
+        if (cshift == 0) return 0; // (only where the constraints are reduced per lane group: evaluate())
+        if (ls.st == LineSearch::SW_V_F || ls.st == LineSearch::W_SHRINK) return -1;
+        if (ls.st == LineSearch::W_GROW) return 1;
+        return 0;
+    }
+    // fs[k] = L(x0 + as[k] p), k < K, for given step lengths.  x, g are not touched.  CS = cshift (a template parameter so
+    // that the whole pass is straight-line code: the reductions of different chunks and trials interleave).
+    template <int K, int CS> __device__ __forceinline__ void evaluate_spec(const double (&as)[K], double (&fs)[K])
+    {
+        static_assert(AUG, "objective-only trials exist in the augmented-Lagrangian kernels only");
+        const int m = A.aug_m;
+        double r[2 * K], cv[K][G::NCH];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double xk[EPT], gl[EPT]; // gl is dead: the compiler drops the gradient arithmetic
+            double xb[EPT];
+            if constexpr (X0_LDS) { // x0 is read from its LDS row again for every trial (FL_SPEC_X0_RELOAD): 16 VGPRs
+                                    // less across the pass, which is what lets four trials fit three waves per SIMD
+                load_pad<NW, EPT>(lds + L_X0, xb);
+                if constexpr (FL_SPEC_X0_RELOAD) asm volatile("" ::: "memory");
+            }
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) xk[e] = (X0_LDS ? xb[e] : x0[X0_LDS ? 0 : e]) + as[k] * p[e];
+            obj.eval(xk, gl, r[2 * k], r[2 * k + 1], n, lds + L_XS);
+#pragma unroll
+            for (int c = 0; c < G::NCH; ++c) cv[k][c] = xk[2 * c] * xk[2 * c] + xk[2 * c + 1] * xk[2 * c + 1];
+        }
+        spar ^= 1; // (the other half's readers are a whole batch behind: see cx_ptr())
+        double *cxs = lds + L_CXS + spar * (K * FL_MAX_CONSTRAINTS);
+        const int tl = G::tid();
+        const int lane = tl & 63;
+        // the block sums: the levels of the fixed tree below the block's lane group, as in evaluate(); values of several
+        // trials share the registers of one pass where the tree leaves room (fl_reduce.hpp)
+#pragma unroll
+        for (int c = 0; c < G::NCH; ++c) {
+            const int j = c * (G::T >> CS) + (tl >> CS);
+            if constexpr (CS == 6) { // block = the wave: value k ends in row group_row(k)
+                double v4[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) v4[k] = cv[k][c];
+                const double q = wave_reduce_group<K>(v4);
+                const int row = lane >> 4;
+                const int k = (K == 4) ? (((row & 1) << 1) | (row >> 1)) : (row >> 1);
+                if ((lane & 15) == 0 && (K == 4 || (row & 1) == 0) && j < m) cxs[k * FL_MAX_CONSTRAINTS + j] = q - 1.0;
+            } else if constexpr (CS == 5) { // block = two rows: two trials per pass (rows 0, 2: the first, rows 1, 3: the second)
+#pragma unroll
+                for (int k = 0; k < K; k += 2) {
+                    const double q = row_allreduce(fold16(cv[k][c], cv[k + 1][c]));
+                    const int kk = k + ((lane >> 4) & 1);
+                    if ((lane & 15) == 0 && j < m) cxs[kk * FL_MAX_CONSTRAINTS + j] = q - 1.0;
+                }
+            } else { // block = one row
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const double q = row_allreduce(cv[k][c]);
+                    if ((lane & 15) == 0 && j < m) cxs[k * FL_MAX_CONSTRAINTS + j] = q - 1.0;
+                }
+            }
+        }
+        R.run(r); // (its barrier also publishes c(x); one wave: LDS operations of a wave complete in order)
+        // lambda.c and c.c of all K trials at once: lane j of DPP row k takes c_j of trial k and lambda_j, and the sums run
+        // down the row in the reference's order, S_j = S_(j-1) + P_j from S = +0 (dot_product, NO.f90:2198) -- m - 1
+        // shifted additions for all trials together instead of 2 m multiply-adds per trial in every lane
+        const int li = lane & (K * FL_MAX_CONSTRAINTS - 1);
+        const double cj = cxs[li], lam = lds[L_LAM + (li & (FL_MAX_CONSTRAINTS - 1))];
+        const double P = lam * cj, Q = cj * cj;
+        double sp = 0.0 + P, sq = 0.0 + Q;
+        for (int i = 1; i < m; ++i) {
+            sp = dpp_shr1_zero(sp) + P;
+            sq = dpp_shr1_zero(sq) + Q;
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const double lc = read_lane(sp, k * FL_MAX_CONSTRAINTS + m - 1), c2 = read_lane(sq, k * FL_MAX_CONSTRAINTS + m - 1);
+            fs[k] = Obj::combine(r[2 * k], r[2 * k + 1]) - lc + miu / 2.0 * c2;
+        }
+    }
+    // The pending request is the objective at ls.a_eval inside one of the loops above: run the loop here up to the trial
+    // at which the reference leaves it, and return that trial's objective value with the machine's variables as its own
+    // steps would have left them (non-exit step: fx=fv; aold=a; fold=fx; a=aold/incr -- sw_v_next, w_shrink_next,
+    // w_grow_next), so that ls.step() of the returned value takes the exit branch (or, never reached in practice, goes
+    // on looping by itself).  Exit tests: SW_V_F / W_SHRINK: Armijo holds or a < 1e-15 (NO.f90:1518-1521, 1543;
+    // 1325-1329, 1337); W_GROW: Armijo fails (NO.f90:1308-1311).
+    template <int K, int CS> __device__ __forceinline__ double fast_forward_cs(int dir)
+    {
+        double aold = ls.aold, fold = ls.fold, a_x, f_x;
+        int consumed = 0;
+        // a / incrmt or a * incrmt: the expression the machine itself forms
+        auto next = [&](double a_) { return uni(dir < 0 ? a_ / ls.incr : a_ * ls.incr); };
+        double as[K];
+        as[0] = ls.a_eval;
+#pragma unroll
+        for (int k = 1; k < K; ++k) as[k] = next(as[k - 1]);
+        for (;;) {
+            double an[K], fs[K]; // the next pass's step lengths do not depend on this pass's values: their divisions overlap it
+            an[0] = next(as[K - 1]);
+#pragma unroll
+            for (int k = 1; k < K; ++k) an[k] = next(an[k - 1]);
+            evaluate_spec<K, CS>(as, fs);
+            int kx = K;
+#pragma unroll
+            for (int k = K - 1; k >= 0; --k) {
+                const double bound = ls.fx0 + ls.c1 * as[k] * ls.phid0;
+                const bool ex = dir < 0 ? (fs[k] <= bound || as[k] < 1e-15) : (fs[k] > bound);
+                if (ex) kx = k;
+            }
+            kx = __builtin_amdgcn_readfirstlane(kx);
+            if (kx < K) {
+                a_x = as[0];
+                f_x = fs[0];
+#pragma unroll
+                for (int k = 1; k < K; ++k) {
+                    if (kx >= k) {
+                        aold = a_x;
+                        fold = f_x;
+                        a_x = as[k];
+                        f_x = fs[k];
+                    }
+                }
+                consumed += kx;
+                break;
+            }
+            aold = as[K - 1];
+            fold = fs[K - 1];
+            consumed += K;
+#pragma unroll
+            for (int k = 0; k < K; ++k) as[k] = an[k];
+        }
+        ls.a = ls.a_eval = uni(a_x);
+        ls.aold = uni(aold);
+        ls.fold = uni(fold);
+        nf += consumed; // (the exit trial itself is counted by advance())
+        // x <- the exit trial's point (the machine asks for the gradient there next).  Neither x nor g is live across the
+        // loop above: x is formed here, and every exit of these loops is followed by a gradient request (SW_V_G /
+        // SW_LAST_G, W_SHRINK_G / W_LAST_G, W_GROW_G) that rewrites g before anything reads it -- said to the register
+        // allocator by leaving g undefined here, which frees 32 VGPRs inside the loop.
+        move(ls.a_eval);
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) asm volatile("" : "=v"(g[k]));
+        return uni(f_x);
+    }
+    template <int K> __device__ __forceinline__ double fast_forward(int dir)
+    {
+        if (cshift == 5) return fast_forward_cs<K, 5>(dir);
+        if (cshift == 6) return fast_forward_cs<K, 6>(dir);
+        return fast_forward_cs<K, 4>(dir);
     }
 
     // Reverse communication with the CALLER's constraints (AugmentedLagrangian's c, cd callbacks, NO.f90:1928-1934):

@@ -26,6 +26,13 @@ template <int CTRL> __device__ __forceinline__ double dpp_add(double v)
     const int hi2 = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
     return v + __hiloint2double(hi2, lo2);
 }
+// lane i of every row <- lane i-1 of the same row, lane 0 <- +0.0 (row_shr:1, bound_ctrl: out-of-row sources read as zero)
+__device__ __forceinline__ double dpp_shr1_zero(double v)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x111, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x111, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 // the four in-row steps; rows may hold different values
 __device__ __forceinline__ double row_allreduce(double v)
 {

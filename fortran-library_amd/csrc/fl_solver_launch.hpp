@@ -11,6 +11,9 @@ namespace fl {
 // occupancy the register allocator is held to (waves per SIMD).  The augmented-Lagrangian L-BFGS / CG kernels at 4
 // elements per thread are bound by the latency of their ~45 objective-only trials per gradient (C5): 130 VGPRs gave
 // 3 waves, capped at 128 they run 4.
+#ifndef FL_AUG18_WPE // with four speculative trials in flight (Solver::SPEC_K) three waves per SIMD would spill 48 VGPRs
+#define FL_AUG18_WPE (FL_SPEC_K >= 4 ? 2 : 3)
+#endif
 template <int NW, int EPT, int OBJ, int METHOD, int AUG> constexpr int min_waves_per_simd()
 {
 #ifdef FL_MIN_WPE
@@ -18,7 +21,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> constexpr int min_waves
 #else
     // (the quartic / Rosenbrock instances would spill 10-14 VGPRs under the cap: left alone)
     if (AUG && EPT == 4 && NW <= 2 && OBJ == FL_OBJ_DIAGQUAD && (METHOD == FL_SOLVER_LBFGS || METHOD == FL_SOLVER_CG)) return 4;
-    if (FL_AUG_LEAN18 && AUG && EPT == 8 && NW == 1 && OBJ == FL_OBJ_DIAGQUAD && (METHOD == FL_SOLVER_LBFGS || METHOD == FL_SOLVER_CG)) return 3; // Solver::AUG_LEAN18 (4 waves: 80-100 spills)
+    if (FL_AUG_LEAN18 && AUG && EPT == 8 && NW == 1 && OBJ == FL_OBJ_DIAGQUAD && (METHOD == FL_SOLVER_LBFGS || METHOD == FL_SOLVER_CG)) return FL_AUG18_WPE; // Solver::AUG_LEAN18 (4 waves: 80-100 spills)
     // SD / CG on them at 8 elements per thread, x0 in LDS (Solver::X0_LDS)
     if (!AUG && OBJ == FL_OBJ_DIAGQUAD && EPT == 8 && NW >= 2 && (METHOD == FL_SOLVER_SD || METHOD == FL_SOLVER_CG) && FL_X0_LDS) return 4;
     // L-BFGS on them at 4 elements per thread (n <= 512): 134-135
@@ -41,21 +44,33 @@ void fl_solve_kernel(SolveArgs A)
     int rq = s.start();
     double fv = 0.0, pv = 0.0, gg = 0.0;
     bool have_g = false; // augmented Lagrangian: objective-only trials skip the gradient until it is asked for
+    constexpr int SK = S::SPEC_K;
     while (rq) {
         // which evaluation the request needs (each form is inlined once)
-        bool f_only = false, full = false;
+        bool f_only = false, full = false, moved = true;
         if (!(rq & FL_REQ_SAME)) {
-            if (!(rq & FL_REQ_NOMOVE)) s.move(s.request_point());
+            moved = !(rq & FL_REQ_NOMOVE);
             if (AUG && !(rq & FL_REQ_G)) f_only = true;
             else full = true;
         } else if (AUG && (rq & FL_REQ_G) && !have_g) { // gradient at the point whose objective is already known
             full = true;
+            moved = false;
+        }
+        if constexpr (SK > 1) { // an objective-only shrink / grow loop of the line search: run it as a tight loop to its exit
+            const int dir = f_only ? s.spec_direction() : 0;
+            if (dir) {
+                fv = s.template fast_forward<SK>(dir); // (leaves x at the exit trial's point)
+                have_g = false;
+                f_only = false;
+            }
         }
         if (AUG && f_only) {
+            s.move(s.request_point());
             s.template evaluate<false>(fv, pv, gg);
             have_g = false;
         }
         if (full) {
+            if (moved) s.move(s.request_point());
             s.template evaluate<true>(fv, pv, gg);
             have_g = true;
         }
