@@ -102,6 +102,35 @@ def main():
             kavg = r["avg_ms"]
     bj = os.path.join(root, "bench.json")  # the bench line of the kernel-trace pass (tools/profile.sh)
     b = json.loads([ln for ln in open(bj).read().splitlines() if ln.startswith("{")][-1])
+    counters_kept = ("SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY",
+                     "SQ_WAIT_INST_ANY", "SQ_WAVES", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR",
+                     "TCC_HIT_sum", "TCC_MISS_sum", "GRBM_GUI_ACTIVE")
+    tj = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        allrec = json.load(open(tj))
+    except (OSError, ValueError):
+        allrec = {}
+    if "only_config" in b:  # one of bench.py's BASELINE configurations (bench.py --only-config cX): keyed by b["pmc_key"]
+        key = b["only_config"]
+        rec = dict(b["pmc_key"])
+        rec.update({"kernel": info["kernel"], "kernel_source_hash": bench.kernel_source_hash(), "vgpr": info["vgpr"],
+                    "lds": info["lds"], "workgroup": info["wg"], "kernel_avg_ms_kernel_trace": kavg,
+                    "iterations_per_launch": b.get("iterations"), "source": sorted(src)})
+        if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+            rec["FETCH_SIZE_KiB_per_launch"], rec["WRITE_SIZE_KiB_per_launch"] = cs["FETCH_SIZE"][0], cs["WRITE_SIZE"][0]
+            rec["traffic_bytes_per_launch"] = (2 * cs["FETCH_SIZE"][0] + cs["WRITE_SIZE"][0]) * 1024
+        if b.get("roofline", {}).get("model_bytes_per_launch"):
+            rec["model_bytes_per_launch"] = b["roofline"]["model_bytes_per_launch"]
+        for c in counters_kept:
+            if c in cs:
+                rec[c] = cs[c][0]
+        if "GRBM_GUI_ACTIVE" in cs and kavg:  # busy shader-clock cycles summed over the 8 XCDs / the kernel's duration
+            rec["shader_clock_hz"] = cs["GRBM_GUI_ACTIVE"][0] / 8.0 / (kavg * 1e-3)
+        allrec[key] = rec
+        json.dump(allrec, open(tj, "w"), indent=1)
+        shutil.copy(bj, os.path.join(dst, f"{tag}_bench.json"))
+        print("recorded", key, "->", tj, "hash", rec["kernel_source_hash"])
+        return
     cfg = b["config"]
     wl = "lbfgs_rosen256" if "Rosenbrock" in cfg["workload"] else "lbfgs_quad1024"
     rec = {"workload": wl, "batch_per_gpu": cfg["batch_per_gpu"], "n": cfg["n"], "memory": cfg["memory"],
@@ -114,16 +143,9 @@ def main():
            "traffic_bytes_per_launch": (2 * cs["FETCH_SIZE"][0] + cs["WRITE_SIZE"][0]) * 1024,
            "model_bytes_per_launch": b["roofline"]["model_bytes_per_launch"],
            "source": sorted(src)}
-    for c in ("SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY",
-              "SQ_WAIT_INST_ANY", "SQ_WAVES", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR",
-              "TCC_HIT_sum", "TCC_MISS_sum", "GRBM_GUI_ACTIVE"):
+    for c in counters_kept:
         if c in cs:
             rec[c] = cs[c][0]
-    tj = os.path.join(ROOT, "profiles", "traffic.json")
-    try:
-        allrec = json.load(open(tj))
-    except (OSError, ValueError):
-        allrec = {}
     allrec["comment"] = ("per-launch PMC figures of the dominant kernel from separate rocprofv3 --pmc passes of the bench.py "
                          "workload (tools/profile.sh, tools/pmc_summary.py --record); traffic_bytes_per_launch = "
                          "(2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts half of a wide read). bench.py uses a "
