@@ -375,12 +375,14 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
 #define FL_SPEC_K 4
 #endif
 #ifndef FL_SPEC_X0_RELOAD
-#define FL_SPEC_X0_RELOAD 1
+#define FL_SPEC_X0_RELOAD 0
 #endif
     static constexpr int SPEC_K = (AUG && (OBJ == FL_OBJ_DIAGQUAD || OBJ == FL_OBJ_QUARTIC) && NW < 8 && FL_SPEC_K > 1) ? FL_SPEC_K : 1;
     static_assert(SPEC_K == 1 || SPEC_K == 2 || SPEC_K == 4, "1, 2 or 4 speculative trials");
     static constexpr int L_CXS = L_CX + 2 * FL_MAX_CONSTRAINTS;  // c(x) of the speculative trials [2][SPEC_K][FL_MAX_CONSTRAINTS]
-    static constexpr int L_SLOT = L_CXS + (SPEC_K > 1 ? 2 * SPEC_K * FL_MAX_CONSTRAINTS : 0); // (c(x) is double buffered: cx_ptr())
+    // ... followed by one slot per thread that takes the stores of the lanes that own no block sum (evaluate_spec stores
+    // from every lane, to a selected address: no exec-mask region splits the pass)
+    static constexpr int L_SLOT = L_CXS + (SPEC_K > 1 ? 2 * SPEC_K * FL_MAX_CONSTRAINTS + G::T : 0); // (c(x) is double buffered: cx_ptr())
     static constexpr int L_XS = (L_SLOT + 16 + 1) & ~1;
     static constexpr int L_G0 = (L_XS + (Obj::LDS_DOUBLES > 0 ? Obj::LDS_DOUBLES : 0) + 1) & ~1;
     // BFGS: s, q, g broadcast arrays; the first one doubles as the g_old parking slot (the
@@ -479,7 +481,16 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
     // augmented Lagrangian
     double miu, cc;
     int outer_it, inner_iters_total;
-    int blk[AUG ? EPT : 1]; // constraint block of each of the thread's elements (-1 = padding)
+    // constraint block of each of the thread's elements (-1 = padding), one signed byte each: four to a register (they are
+    // live for the whole solve; eight registers of them were what kept four speculative trials from three waves per SIMD)
+    // (not in the 512-thread kernels: there the unpacking's temporaries are what spills)
+    static constexpr int BLK_PER = (NW < 8) ? 4 : 1;
+    int blkp[AUG ? (EPT + BLK_PER - 1) / BLK_PER : 1];
+    __device__ __forceinline__ int blk(int k) const
+    {
+        if constexpr (BLK_PER == 1) return blkp[k];
+        else return (blkp[k >> 2] << (24 - 8 * (k & 3))) >> 24;
+    }
     int cpar;               // which of the two c(x) buffers holds the last evaluation's constraints
     int spar;               // ... and which half of the speculative trials' buffers the last batch wrote
     int cshift;             // log2 of the lanes per constraint block where blocks are aligned lane groups (4, 5, 6), else 0
@@ -564,7 +575,10 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
 #ifndef FL_UNI_LEAN
 #define FL_UNI_LEAN 2
 #endif
-    static constexpr int UNI_LEVEL = LEAN ? FL_UNI_LEAN : FL_UNI_LEVEL;
+#ifndef FL_UNI_AUG18
+#define FL_UNI_AUG18 2
+#endif
+    static constexpr int UNI_LEVEL = LEAN ? FL_UNI_LEAN : (AUG_LEAN18 ? FL_UNI_AUG18 : FL_UNI_LEVEL);
     __device__ __forceinline__ void park()
     {
         if constexpr (PARK && !HESS_RCI) store_user<NW, EPT>(A.x + (size_t)prob * n, n, x); // (RCI: x is already there)
@@ -603,15 +617,21 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
         miu = 0.0;
         cshift = 0;
         cpar = 0;
-        spar = 0;
+        if constexpr (SPEC_K > 1) spar = 0;
         if constexpr (AUG) {
             if constexpr (OBJ != FL_OBJ_EXTERNAL) { // the built-in constraint family: block spheres
                 const int w = n / A.aug_m;
                 if (w > 0 && (2 * G::T) % w == 0) cshift = (w == 128) ? 6 : (w == 64 ? 5 : (w == 32 ? 4 : 0));
+                if constexpr (BLK_PER > 1) {
+#pragma unroll
+                    for (int q = 0; q < (EPT + BLK_PER - 1) / BLK_PER; ++q) blkp[q] = 0;
+                }
 #pragma unroll
                 for (int k = 0; k < EPT; ++k) {
                     const int e = G::e0(k >> 1) + (k & 1);
-                    blk[k] = (e < n) ? e / w : -1;
+                    const int bk = (e < n) ? e / w : -1;
+                    if constexpr (BLK_PER == 1) blkp[k] = bk;
+                    else blkp[k >> 2] |= (bk & 0xff) << (8 * (k & 3)); // (aug_m <= FL_MAX_CONSTRAINTS = 16)
                 }
             }
             miu = A.miu0 > 1.0 ? A.miu0 : 1.0; // miu=max(1d0,miu0)
@@ -664,7 +684,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
                 if (j < m) {
 #pragma unroll
                     for (int k = 0; k < EPT; ++k) {
-                        const double t = (blk[k] == j) ? x[k] * x[k] : 0.0;
+                        const double t = (blk(k) == j) ? x[k] * x[k] : 0.0;
                         acc = (k == 0) ? t : acc + t;
                     }
                 }
@@ -733,8 +753,8 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
             if constexpr (!WANT_G) return;
 #pragma unroll
             for (int k = 0; k < EPT; ++k) {
-                if (blk[k] >= 0) {
-                    int j = blk[k];
+                if (blk(k) >= 0) {
+                    int j = blk(k);
                     asm volatile("" : "+v"(j)); // (the LDS addresses of c_j, lambda_j are formed here, not kept from init())
                     const double v = miu * cxs[j] - lds[L_LAM + j];
                     g[k] = g[k] + (2.0 * x[k]) * v; // Ldx=Ldx+matmul(cdx,miu*cx-lambda)
@@ -770,13 +790,13 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
     }
 
     // ---------------------------------------------------------------- speculative objective-only trials (SPEC_K)
-    // +1: the pending objective-only request opens (or continues) a loop a <- a * incrmt, -1: a <- a / incrmt, 0: neither
-    __device__ __forceinline__ int spec_direction() const
+    // is the pending objective-only request inside one of the loops a <- a / incrmt (StrongWolfe's and Wolfe's Armijo-violated
+    // branches)?  (Wolfe's growing loop a <- a * incrmt, NO.f90:1308-1313, stays with the machine: one more copy of the
+    // pass for a searcher nobody picks by default.)
+    __device__ __forceinline__ bool spec_shrinking() const
     {
-        if (cshift == 0) return 0; // (only where the constraints are reduced per lane group: evaluate())
-        if (ls.st == LineSearch::SW_V_F || ls.st == LineSearch::W_SHRINK) return -1;
-        if (ls.st == LineSearch::W_GROW) return 1;
-        return 0;
+        if (cshift == 0) return false; // (only where the constraints are reduced per lane group: evaluate())
+        return ls.st == LineSearch::SW_V_F || ls.st == LineSearch::W_SHRINK;
     }
     // fs[k] = L(x0 + as[k] p), k < K, for given step lengths.  x, g are not touched.  CS = cshift (a template parameter so
     // that the whole pass is straight-line code: the reductions of different chunks and trials interleave).
@@ -804,6 +824,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
         double *cxs = lds + L_CXS + spar * (K * FL_MAX_CONSTRAINTS);
         const int tl = G::tid();
         const int lane = tl & 63;
+        double *junk = lds + L_CXS + 2 * K * FL_MAX_CONSTRAINTS + tl;
         // the block sums: the levels of the fixed tree below the block's lane group, as in evaluate(); values of several
         // trials share the registers of one pass where the tree leaves room (fl_reduce.hpp)
 #pragma unroll
@@ -816,19 +837,20 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
                 const double q = wave_reduce_group<K>(v4);
                 const int row = lane >> 4;
                 const int k = (K == 4) ? (((row & 1) << 1) | (row >> 1)) : (row >> 1);
-                if ((lane & 15) == 0 && (K == 4 || (row & 1) == 0) && j < m) cxs[k * FL_MAX_CONSTRAINTS + j] = q - 1.0;
+                const bool own = (lane & 15) == 0 && (K == 4 || (row & 1) == 0) && j < m;
+                *(own ? cxs + k * FL_MAX_CONSTRAINTS + j : junk) = q - 1.0;
             } else if constexpr (CS == 5) { // block = two rows: two trials per pass (rows 0, 2: the first, rows 1, 3: the second)
 #pragma unroll
                 for (int k = 0; k < K; k += 2) {
                     const double q = row_allreduce(fold16(cv[k][c], cv[k + 1][c]));
                     const int kk = k + ((lane >> 4) & 1);
-                    if ((lane & 15) == 0 && j < m) cxs[kk * FL_MAX_CONSTRAINTS + j] = q - 1.0;
+                    *(((lane & 15) == 0 && j < m) ? cxs + kk * FL_MAX_CONSTRAINTS + j : junk) = q - 1.0;
                 }
             } else { // block = one row
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     const double q = row_allreduce(cv[k][c]);
-                    if ((lane & 15) == 0 && j < m) cxs[k * FL_MAX_CONSTRAINTS + j] = q - 1.0;
+                    *(((lane & 15) == 0 && j < m) ? cxs + k * FL_MAX_CONSTRAINTS + j : junk) = q - 1.0;
                 }
             }
         }
@@ -852,16 +874,14 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
     }
     // The pending request is the objective at ls.a_eval inside one of the loops above: run the loop here up to the trial
     // at which the reference leaves it, and return that trial's objective value with the machine's variables as its own
-    // steps would have left them (non-exit step: fx=fv; aold=a; fold=fx; a=aold/incr -- sw_v_next, w_shrink_next,
-    // w_grow_next), so that ls.step() of the returned value takes the exit branch (or, never reached in practice, goes
-    // on looping by itself).  Exit tests: SW_V_F / W_SHRINK: Armijo holds or a < 1e-15 (NO.f90:1518-1521, 1543;
-    // 1325-1329, 1337); W_GROW: Armijo fails (NO.f90:1308-1311).
-    template <int K, int CS> __device__ __forceinline__ double fast_forward_cs(int dir)
+    // steps would have left them (non-exit step: fx=fv; aold=a; fold=fx; a=aold/incr -- sw_v_next, w_shrink_next),
+    // so that ls.step() of the returned value takes the exit branch.  Exit test of SW_V_F / W_SHRINK: Armijo holds or
+    // a < 1e-15 (NO.f90:1518-1521, 1543; 1325-1329, 1337).
+    template <int K, int CS> __device__ __forceinline__ double fast_forward_cs()
     {
         double aold = ls.aold, fold = ls.fold, a_x, f_x;
         int consumed = 0;
-        // a / incrmt or a * incrmt: the expression the machine itself forms
-        auto next = [&](double a_) { return uni(dir < 0 ? a_ / ls.incr : a_ * ls.incr); };
+        auto next = [&](double a_) { return uni(a_ / ls.incr); }; // a=aold/incrmt: the expression the machine itself forms
         double as[K];
         as[0] = ls.a_eval;
 #pragma unroll
@@ -872,25 +892,24 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
 #pragma unroll
             for (int k = 1; k < K; ++k) an[k] = next(an[k - 1]);
             evaluate_spec<K, CS>(as, fs);
-            int kx = K;
+            unsigned exits = 0; // bit k: the reference leaves the loop at trial k (Armijo holds, or a < 1e-15)
 #pragma unroll
-            for (int k = K - 1; k >= 0; --k) {
+            for (int k = 0; k < K; ++k) {
                 const double bound = ls.fx0 + ls.c1 * as[k] * ls.phid0;
-                const bool ex = dir < 0 ? (fs[k] <= bound || as[k] < 1e-15) : (fs[k] > bound);
-                if (ex) kx = k;
+                exits |= (unsigned)((fs[k] <= bound) | (as[k] < 1e-15)) << k;
             }
-            kx = __builtin_amdgcn_readfirstlane(kx);
-            if (kx < K) {
+            exits = __builtin_amdgcn_readfirstlane(exits);
+            if (exits) {
+                const int kx = __builtin_ctz(exits);
                 a_x = as[0];
                 f_x = fs[0];
 #pragma unroll
                 for (int k = 1; k < K; ++k) {
-                    if (kx >= k) {
-                        aold = a_x;
-                        fold = f_x;
-                        a_x = as[k];
-                        f_x = fs[k];
-                    }
+                    const bool take = kx >= k;
+                    aold = take ? a_x : aold;
+                    fold = take ? f_x : fold;
+                    a_x = take ? as[k] : a_x;
+                    f_x = take ? fs[k] : f_x;
                 }
                 consumed += kx;
                 break;
@@ -907,18 +926,18 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
         nf += consumed; // (the exit trial itself is counted by advance())
         // x <- the exit trial's point (the machine asks for the gradient there next).  Neither x nor g is live across the
         // loop above: x is formed here, and every exit of these loops is followed by a gradient request (SW_V_G /
-        // SW_LAST_G, W_SHRINK_G / W_LAST_G, W_GROW_G) that rewrites g before anything reads it -- said to the register
+        // SW_LAST_G, W_SHRINK_G / W_LAST_G) that rewrites g before anything reads it -- said to the register
         // allocator by leaving g undefined here, which frees 32 VGPRs inside the loop.
         move(ls.a_eval);
 #pragma unroll
         for (int k = 0; k < EPT; ++k) asm volatile("" : "=v"(g[k]));
         return uni(f_x);
     }
-    template <int K> __device__ __forceinline__ double fast_forward(int dir)
+    template <int K> __device__ __forceinline__ double fast_forward()
     {
-        if (cshift == 5) return fast_forward_cs<K, 5>(dir);
-        if (cshift == 6) return fast_forward_cs<K, 6>(dir);
-        return fast_forward_cs<K, 4>(dir);
+        if (cshift == 5) return fast_forward_cs<K, 5>();
+        if (cshift == 6) return fast_forward_cs<K, 6>();
+        return fast_forward_cs<K, 4>();
     }
 
     // Reverse communication with the CALLER's constraints (AugmentedLagrangian's c, cd callbacks, NO.f90:1928-1934):
@@ -1128,7 +1147,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
                 for (int k = 0; k < EPT; ++k) {
                     const int i = G::e0(k >> 1) + (k & 1);
                     const double t = (i == j) ? 2.0 * vb : 0.0;
-                    const double pterm = (blk[k] == bj) ? (2.0 * x[k]) * xj2 : 0.0;
+                    const double pterm = (blk(k) == bj) ? (2.0 * x[k]) * xj2 : 0.0;
                     h[k] = (h[k] + t) + pterm;
                 }
                 store_pad<NW, EPT>(Hm + (size_t)j * NPAD, h);

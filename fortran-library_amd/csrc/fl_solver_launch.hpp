@@ -11,8 +11,8 @@ namespace fl {
 // occupancy the register allocator is held to (waves per SIMD).  The augmented-Lagrangian L-BFGS / CG kernels at 4
 // elements per thread are bound by the latency of their ~45 objective-only trials per gradient (C5): 130 VGPRs gave
 // 3 waves, capped at 128 they run 4.
-#ifndef FL_AUG18_WPE // with four speculative trials in flight (Solver::SPEC_K) three waves per SIMD would spill 48 VGPRs
-#define FL_AUG18_WPE (FL_SPEC_K >= 4 ? 2 : 3)
+#ifndef FL_AUG18_WPE
+#define FL_AUG18_WPE 3
 #endif
 template <int NW, int EPT, int OBJ, int METHOD, int AUG> constexpr int min_waves_per_simd()
 {
@@ -47,30 +47,28 @@ void fl_solve_kernel(SolveArgs A)
     constexpr int SK = S::SPEC_K;
     while (rq) {
         // which evaluation the request needs (each form is inlined once)
-        bool f_only = false, full = false, moved = true;
+        bool f_only = false, full = false;
         if (!(rq & FL_REQ_SAME)) {
-            moved = !(rq & FL_REQ_NOMOVE);
             if (AUG && !(rq & FL_REQ_G)) f_only = true;
             else full = true;
+            bool forwarded = false;
+            if constexpr (SK > 1) { // an objective-only shrinking loop of the line search: run it as a tight loop to its exit
+                if (f_only && s.spec_shrinking()) {
+                    fv = s.template fast_forward<SK>(); // (leaves x at the exit trial's point)
+                    have_g = false;
+                    f_only = false;
+                    forwarded = true;
+                }
+            }
+            if (!forwarded && !(rq & FL_REQ_NOMOVE)) s.move(s.request_point());
         } else if (AUG && (rq & FL_REQ_G) && !have_g) { // gradient at the point whose objective is already known
             full = true;
-            moved = false;
-        }
-        if constexpr (SK > 1) { // an objective-only shrink / grow loop of the line search: run it as a tight loop to its exit
-            const int dir = f_only ? s.spec_direction() : 0;
-            if (dir) {
-                fv = s.template fast_forward<SK>(dir); // (leaves x at the exit trial's point)
-                have_g = false;
-                f_only = false;
-            }
         }
         if (AUG && f_only) {
-            s.move(s.request_point());
             s.template evaluate<false>(fv, pv, gg);
             have_g = false;
         }
         if (full) {
-            if (moved) s.move(s.request_point());
             s.template evaluate<true>(fv, pv, gg);
             have_g = true;
         }
