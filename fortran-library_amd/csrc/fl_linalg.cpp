@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/fl_nlopt.h"
+#include "fl_host.hpp"
 
 namespace {
 
@@ -45,6 +46,19 @@ void gemm(bool transA, const double *A, const double *B, double *C, int M, int K
 } // namespace
 
 extern "C" {
+
+// The library's replacement of MKL's djacobi (the reference: NO.f90:676, 981, 1067, 1258, 1779, 1833), with MKL's own
+// argument convention -- fcn(m, n, x, f) by reference, fjac(m, n) column-major, the value TR_SUCCESS = 1501 returned --
+// and MKL's step rule (fl_host.hpp).  Host code: no device is needed.
+int fl_djacobi(void (*fcn)(const int *, const int *, const double *, double *), const int *n, const int *m, double *fjac,
+               double *x, const double *eps)
+{
+    if (!fcn || !n || !m || !fjac || !x || !eps || *n <= 0 || *m <= 0 || !(*eps > 0.0)) return 1502; // TR_INVALID_OPTION
+    std::vector<double> fp(*m), fm(*m);
+    fl::central_difference_jacobian([&](const double *p, double *f) { fcn(m, n, p, f); }, *n, *m, fjac, x, *eps, fp.data(),
+                                    fm.data());
+    return 1501;
+}
 
 // subroutine My_dgemm(A,B,C,M,K,N): C = A . B (LinearAlgebra.f90:182-188)
 void __linearalgebra_MOD_my_dgemm(const double *A, const double *B, double *C, const int *M, const int *K, const int *N)
@@ -151,16 +165,9 @@ static void trust_region(res_cb fd, jac_cb Jacobian, double *x, int M, int N, co
             (void)Jacobian(J.data(), xx, M, N);
             return;
         }
-        std::vector<double> xp(xx, xx + N);
-        for (int j = 0; j < N; ++j) {
-            const double h = 1e-8 * std::fmax(1.0, std::fabs(xx[j]));
-            xp[j] = xx[j] + h;
-            fd(rp.data(), xp.data(), M, N);
-            xp[j] = xx[j] - h;
-            fd(rm.data(), xp.data(), M, N);
-            xp[j] = xx[j];
-            for (int i = 0; i < M; ++i) J[(size_t)j * M + i] = (rp[i] - rm[i]) / (2.0 * h);
-        }
+        std::vector<double> xp(xx, xx + N); // djacobi(fd_j,N,M,J,x,1d-8), NO.f90:1779: MKL's step rule (fl_host.hpp)
+        fl::central_difference_jacobian([&](const double *p, double *f) { fd(f, p, M, N); }, N, M, J.data(), xp.data(), 1e-8,
+                                        rp.data(), rm.data());
     };
     auto normal_equations = [&]() { // A = J^T J, g = J^T r on the GPU
         gemm(true, J.data(), J.data(), A.data(), N, M, N);

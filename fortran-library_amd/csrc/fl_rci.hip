@@ -465,23 +465,15 @@ static HostObjective host_objective(f_cb f, fd_cb fd, ffd_cb f_fd)
 }
 
 // fdd absent: the reference differentiates f' numerically with MKL's djacobi(fd_j,dim,dim,H,x,1d-8) (NO.f90:676,
-// 981, 1067, 1258) -- central differences; MKL is closed and the reference does not state its step rule, so this
-// branch is "parity unpinned" (DESIGN.md).  Here: column j = (f'(x + h e_j) - f'(x - h e_j)) / (2h),
-// h = 1e-8 * max(1, |x_j|), 2n gradient calls per Hessian like djacobi.
+// 981, 1067, 1258).  Same central differences with djacobi's own step rule (fl_host.hpp: central_difference_jacobian,
+// pinned bit for bit to the real MKL routine by tests/golden/mkl_djacobi.npz), 2n gradient calls per Hessian.
 static std::function<void(double *, const double *, int)>
 central_difference_hessian(std::function<void(double *, const double *, int)> grad)
 {
     return [grad](double *H, const double *x, int n) {
         std::vector<double> xp(x, x + n), gp(n), gm(n);
-        for (int j = 0; j < n; ++j) {
-            const double h = 1e-8 * std::fmax(1.0, std::fabs(x[j]));
-            xp[j] = x[j] + h;
-            grad(gp.data(), xp.data(), n);
-            xp[j] = x[j] - h;
-            grad(gm.data(), xp.data(), n);
-            xp[j] = x[j];
-            for (int i = 0; i < n; ++i) H[(size_t)j * n + i] = (gp[i] - gm[i]) / (2.0 * h);
-        }
+        fl::central_difference_jacobian([&](const double *xx, double *g) { grad(g, xx, n); }, n, n, H, xp.data(), 1e-8, gp.data(),
+                                    gm.data());
     };
 }
 static std::function<void(double *, const double *, int)> central_difference_hessian(fd_cb fd)

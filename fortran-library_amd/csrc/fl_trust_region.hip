@@ -8,7 +8,8 @@
 // construction (same stationary points, own path).  Per step and problem: A = J^T J, g = J^T r on the f64 matrix cores
 // (fl_dgemm_strided), (A + mu I) d = -g by fl_dposv_batched, trial point x + d projected into the box; gain ratio
 // rho = (|r|^2 - |r_new|^2) / (d.(mu d - g)) decides: accept (mu *= max(1/3, 1 - (2 rho - 1)^3), new Jacobian wanted)
-// or reject (mu *= nu, nu *= 2, new trial from the same A, g).  The caller evaluates residuals and Jacobians for the
+// or reject (mu *= nu, nu *= 2, new trial from the same A, g: they are kept per problem and renewed only by a Jacobian
+// the problem asked for).  The caller evaluates residuals and Jacobians for the
 // whole batch wherever the request bits ask: FL_TRS_REQ_R (1) residual at x_dev[k], FL_TRS_REQ_J (2) Jacobian at
 // x_dev[k], FL_TRS_REQ_AGAIN (4) nothing to evaluate for this problem, call again; 0 finished.
 #include <hip/hip_runtime.h>
@@ -27,6 +28,7 @@ enum { TP_INIT = 0, TP_TRIAL = 1, TP_JAC = 2, TP_DONE = 3, TP_SOLVE = 4 };
 struct TrsState {
     double mu, nu, f2, f2_0, pred;
     int phase, it, stepit, reason, have_mu;
+    int fresh; // this step consumed a Jacobian the problem had asked for (TP_INIT, TP_JAC): A = J^T J, g = J^T r are renewed
 };
 
 __device__ __forceinline__ double block_sum(double v, double *red)
@@ -71,6 +73,7 @@ __global__ __launch_bounds__(256) void trs_take_kernel(int M, int N, int maxit, 
             st.f2 = st.f2_0 = f2;
             st.phase = (sqrt(f2) < precision) ? TP_DONE : TP_SOLVE;
             st.reason = (st.phase == TP_DONE) ? 3 : 1;
+            st.fresh = 1;
             S[k] = st;
         }
     } else if (st.phase == TP_TRIAL) {
@@ -106,9 +109,25 @@ __global__ __launch_bounds__(256) void trs_take_kernel(int M, int N, int maxit, 
     } else { // TP_JAC: the caller has written the Jacobian at xcur
         if (tid == 0) {
             st.phase = TP_SOLVE;
+            st.fresh = 1;
             S[k] = st;
         }
     }
+}
+
+// A <- J^T J, g <- J^T r of this step -- only for the problems whose step consumed a Jacobian they had asked for.  A
+// problem that retries with more damping (rejected trial, Cholesky failure) keeps the A, g of its current point: what
+// the caller's J array holds for it meanwhile (nothing was requested) does not matter.
+__global__ __launch_bounds__(256) void trs_commit_kernel(int N, TrsState *S, const double *A_new, const double *g_new, double *A,
+                                                         double *g)
+{
+    const int k = blockIdx.x, tid = threadIdx.x;
+    if (!S[k].fresh) return;
+    const size_t nn = (size_t)N * N;
+    for (size_t e = tid; e < nn; e += 256) A[(size_t)k * nn + e] = A_new[(size_t)k * nn + e];
+    for (int i = tid; i < N; i += 256) g[(size_t)k * N + i] = g_new[(size_t)k * N + i];
+    __syncthreads();
+    if (tid == 0) S[k].fresh = 0;
 }
 
 // Ap = A + mu I in the padded layout of fl_dposv_batched, rhs = -g (identity / zero for problems that do not solve)
@@ -214,7 +233,7 @@ __global__ void trs_init_kernel(int batch, TrsState *S)
     st.mu = st.pred = st.f2 = st.f2_0 = 0.0;
     st.nu = 2.0;
     st.phase = TP_INIT;
-    st.it = st.stepit = st.have_mu = 0;
+    st.it = st.stepit = st.have_mu = st.fresh = 0;
     st.reason = 1;
     S[k] = st;
 }
@@ -243,7 +262,7 @@ struct fl_trs {
     int batch, M, N, ld, maxit, maxstepit, first;
     double precision, minstep;
     fl::TrsState *S;
-    double *xcur, *r, *A, *g, *Ap, *d, *low, *up;
+    double *xcur, *r, *A, *g, *A_new, *g_new, *Ap, *d, *low, *up;
     int32_t *info;
     hipStream_t st;
 };
@@ -253,7 +272,7 @@ extern "C" {
 int fl_trust_region_destroy(fl_trs *h)
 {
     if (!h) return FL_OK;
-    void *bufs[] = {h->S, h->xcur, h->r, h->A, h->g, h->Ap, h->d, h->low, h->up, h->info};
+    void *bufs[] = {h->S, h->xcur, h->r, h->A, h->g, h->A_new, h->g_new, h->Ap, h->d, h->low, h->up, h->info};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     delete h;
@@ -280,6 +299,7 @@ int fl_trust_region_create(fl_trs **out, int batch, int M, int N, const double *
     bool ok = hipMalloc((void **)&h->S, B * sizeof(fl::TrsState)) == hipSuccess &&
               hipMalloc((void **)&h->xcur, B * n * 8) == hipSuccess && hipMalloc((void **)&h->r, B * (size_t)M * 8) == hipSuccess &&
               hipMalloc((void **)&h->A, B * n * n * 8) == hipSuccess && hipMalloc((void **)&h->g, B * n * 8) == hipSuccess &&
+              hipMalloc((void **)&h->A_new, B * n * n * 8) == hipSuccess && hipMalloc((void **)&h->g_new, B * n * 8) == hipSuccess &&
               hipMalloc((void **)&h->Ap, B * n * (size_t)h->ld * 8) == hipSuccess &&
               hipMalloc((void **)&h->d, B * n * 8) == hipSuccess && hipMalloc((void **)&h->info, B * 4) == hipSuccess;
     if (ok && low_dev && up_dev) {
@@ -309,13 +329,15 @@ int fl_trust_region_step(fl_trs *h, double *x_dev, const double *r_dev, const do
         if (!r_dev || !J_dev) return FL_ERR_INVALID_ARGUMENT;
         hipLaunchKernelGGL(fl::trs_take_kernel, dim3(B), dim3(256), 0, h->st, M, N, h->maxit, h->maxstepit, h->precision, h->S,
                            h->xcur, x_dev, h->r, r_dev);
-        // A = J^T J, g = J^T r for every problem (the caller leaves the Jacobians it was not asked for as they were, so a
-        // problem that only retries with more damping recomputes the same A, g)
-        int rc = fl_dgemm_strided(1, 0, N, M, N, 1.0, J_dev, M, (size_t)M * N, J_dev, M, (size_t)M * N, 0.0, h->A, N,
+        // J^T J and J^T r of what the caller's arrays hold, for every problem (one strided-batch product each); only the
+        // problems that had ASKED for a Jacobian take them over (trs_commit_kernel) -- a caller is free to rewrite J for
+        // every problem on every step, at whatever point x_dev holds for it
+        int rc = fl_dgemm_strided(1, 0, N, M, N, 1.0, J_dev, M, (size_t)M * N, J_dev, M, (size_t)M * N, 0.0, h->A_new, N,
                                   (size_t)N * N, B, 0, h->st);
         if (rc != FL_OK) return rc;
-        rc = fl_dgemm_strided(1, 0, N, M, 1, 1.0, J_dev, M, (size_t)M * N, h->r, M, (size_t)M, 0.0, h->g, N, (size_t)N, B, 0, h->st);
+        rc = fl_dgemm_strided(1, 0, N, M, 1, 1.0, J_dev, M, (size_t)M * N, h->r, M, (size_t)M, 0.0, h->g_new, N, (size_t)N, B, 0, h->st);
         if (rc != FL_OK) return rc;
+        hipLaunchKernelGGL(fl::trs_commit_kernel, dim3(B), dim3(256), 0, h->st, N, h->S, h->A_new, h->g_new, h->A, h->g);
         hipLaunchKernelGGL(fl::trs_build_kernel, dim3(B), dim3(256), 0, h->st, N, h->ld, h->S, h->A, h->g, h->Ap, h->d);
         rc = fl_dposv_batched(B, N, h->Ap, h->d, h->info, h->st);
         if (rc != FL_OK) return rc;

@@ -289,6 +289,15 @@ int fl_rci_step_auglag(fl_rci *handle, double *x_dev, const double *f_dev, const
                        const double *cd_dev, int32_t *request_dev);
 int fl_rci_results_auglag(fl_rci *handle, double *cnorm2_dev, int32_t *outer_dev);
 
+/* ---- central-difference Jacobian: the library's replacement of MKL's djacobi, which the reference calls for f'' when
+ * the caller passes no fdd (NO.f90:676, 981, 1067, 1258: djacobi(fd_j,dim,dim,H,x,1d-8)) and for TrustRegion's Jacobian
+ * (NO.f90:1779, 1833).  MKL's argument convention: fcn(m, n, x, f) with everything by reference, fjac(m, n) column-major,
+ * returns 1501 (TR_SUCCESS) or 1502 (invalid argument); x is restored.  Step rule = djacobi's own, held to the real MKL
+ * routine bit for bit (tests/golden/mkl_djacobi.npz):  |x_j| > eps: f at x_j (1 +- eps), h = eps x_j;  else f at
+ * x_j +- eps, h = eps;  fjac(:,j) = (f_plus - f_minus) * (0.5 / h).  Host code, 2n calls of fcn. */
+int fl_djacobi(void (*fcn)(const int *m, const int *n, const double *x, double *f), const int *n, const int *m,
+               double *fjac, double *x, const double *eps);
+
 /* ---- TrustRegion (NO.f90:1728-1906) for a batch, on the device, by reverse communication ------------------------
  * Solves f'(x) = 0 in the least-squares sense (M equations, N unknowns, M >= N; optional box low <= x <= up shared by
  * the batch) for `batch` independent problems.  The reference wraps MKL's closed dtrnlsp solver; this is the library's
@@ -297,8 +306,10 @@ int fl_rci_results_auglag(fl_rci *handle, double *cnorm2_dev, int32_t *outer_dev
  *   fl_trust_region_step(h, x_dev, r_dev, J_dev, request_dev): first call x_dev [batch][N] = starting points (r_dev,
  *   J_dev may be NULL); afterwards r_dev [batch][M] = f'(x) and J_dev [batch][N][M] = the M x N Jacobian, column-major
  *   (the Fortran array Jacobian(M,N)), evaluated at x_dev[k] where request_dev[k] asked for them: bit FL_TRS_REQ_R (1)
- *   residual, FL_TRS_REQ_J (2) Jacobian (arrays of problems not asked are left as they were), FL_TRS_REQ_AGAIN (4)
- *   nothing to evaluate for this problem but it has not finished, 0 finished (x_dev[k] = the solution).
+ *   residual, FL_TRS_REQ_J (2) Jacobian, FL_TRS_REQ_AGAIN (4) nothing to evaluate for this problem but it has not
+ *   finished, 0 finished (x_dev[k] = the solution).  What the arrays hold for a problem that did NOT ask is ignored:
+ *   J^T J and J^T r are kept per problem inside the handle and renewed only from a Jacobian the problem requested, so
+ *   a caller may as well evaluate r and J for the whole batch at x_dev on every step.
  * fl_trust_region_results: ||f'(x)||_2, accepted iterations, stopping reason (1 MaxIteration, 2 MaxStepIteration,
  * 3 Precision met, 4 stationary point of |f'|^2, 5 MinStepLength). */
 #define FL_TRS_REQ_R 1

@@ -126,5 +126,37 @@ def test_batched_trust_region_larger_overdetermined_systems():
     out = NLO.TrustRegion(x, fun, m, MaxIteration=100, Precision=1e-12, MinStepLength=1e-13)
     r, J = fun(x, None)
     grad = torch.einsum("bnm,bm->bn", J, r)
-    assert float(grad.abs().max()) < 1e-6 * float(r.norm(dim=1).max())  # a non-zero-residual fit: first-order stationarity
+    # a non-zero-residual fit: first-order stationarity.  The bar is the dependency's own: on this family the real MKL
+    # dtrnlsp stops (criterion 6) at |J^T r| = 1.3e-7 |r| (tests/golden/mkl_trnlsp.npz: fit_n20, fit_n40); the
+    # library's iteration is held to better than that here and to MKL's end points in tests/test_mkl_pins.py
+    assert float(grad.abs().max()) < 1e-7 * float(r.norm(dim=1).max())
     assert np.all(np.isin(out["reason"].cpu().numpy(), (4, 5, 3, 2)))
+
+
+def test_batched_trust_region_ignores_arrays_it_did_not_ask_for():
+    """A rejected or retried step must be rebuilt from J^T J, J^T r of the problem's CURRENT point, whatever the
+    caller's arrays hold meanwhile: a caller that poisons r / J of every problem whose request bits did not ask for them
+    gets bit for bit the answer of one that evaluates everything everywhere -- with rejections on the way (far start,
+    tiny first damping)."""
+    NLO = _nlo()
+    dev = torch.device("cuda:0")
+    B, n = 16, 12
+    rng = np.random.default_rng(9)
+    x0 = np.tile(np.where(np.arange(n) % 2 == 0, -3.0, 4.0), (B, 1)) + 0.3 * rng.standard_normal((B, n))
+    seen = {"again": 0, "r_only": 0}
+
+    def poisoned(xx, rq):
+        r, J = _rosen_res_jac(xx)
+        r[(rq & 1) == 0] = float("nan")
+        J[(rq & 2) == 0] = float("nan")
+        seen["again"] += int(((rq & 4) != 0).sum())
+        seen["r_only"] += int(((rq & 3) == 1).sum())
+        return r, J
+    xa = torch.tensor(x0, device=dev)
+    oa = NLO.TrustRegion(xa, lambda xx, rq: _rosen_res_jac(xx), 2 * (n - 1), MaxIteration=300, MaxStepIteration=60, Precision=1e-10,
+                         check_every=1)
+    xb = torch.tensor(x0, device=dev)
+    ob = NLO.TrustRegion(xb, poisoned, 2 * (n - 1), MaxIteration=300, MaxStepIteration=60, Precision=1e-10, check_every=1)
+    assert seen["r_only"] > int(ob["iters"].sum())  # more trial points than accepted steps: some trials were rejected
+    assert torch.equal(xa, xb) and torch.equal(oa["iters"], ob["iters"]) and torch.equal(oa["reason"], ob["reason"])
+    assert np.all(ob["reason"].cpu().numpy() == 3) and float((xb - 1.0).abs().max()) < 1e-8
