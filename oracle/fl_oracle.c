@@ -835,22 +835,40 @@ int flo_dposv_lower(double *A, double *b, int n)
     return 0;
 }
 
-/* own central-difference Jacobian of the gradient; stands in for MKL djacobi
- * (NO.f90:676, 981), whose step rule is closed source: PARITY UNPINNED */
-static void central_hessian(flo_fd_t fd, double *H, double *x, int n, void *ctx, flo_stats *st)
+/* central-difference Jacobian of the gradient: MKL's djacobi(fd_j,dim,dim,H,x,1d-8) (NO.f90:676, 981, 1067, 1258).
+ * MKL is closed; its step rule was read off the points at which the real routine of the build image calls fcn
+ * (tools/make_mkl_golden.py) and this restatement returns the real routine's bits on tests/golden/mkl_djacobi.npz
+ * (tests/test_mkl_pins.py):  |x_j| > eps: f' at x_j (1 +- eps), h = eps x_j;  else f' at x_j +- eps, h = eps;
+ * H(:,j) = (f'_plus - f'_minus) * (0.5 / h). */
+void flo_central_hessian(flo_fd_t fd, double *H, double *x, int n, void *ctx, flo_stats *st)
 {
+    const double eps = 1e-8;
     double *gp = (double *)malloc(sizeof(double) * 2 * (size_t)n), *gm = gp + n;
     for (int j = 0; j < n; ++j) {
-        double xj = x[j], h = 1e-8 * (fabs(xj) > 1.0 ? fabs(xj) : 1.0);
-        x[j] = xj + h;
-        fd(gp, x, n, ctx);
-        x[j] = xj - h;
-        fd(gm, x, n, ctx);
+        double xj = x[j], h;
+        if (fabs(xj) > eps) {
+            h = eps * xj;
+            x[j] = xj * (1.0 + eps);
+            fd(gp, x, n, ctx);
+            x[j] = xj * (1.0 - eps);
+            fd(gm, x, n, ctx);
+        } else {
+            h = eps;
+            x[j] = xj + eps;
+            fd(gp, x, n, ctx);
+            x[j] = xj - eps;
+            fd(gm, x, n, ctx);
+        }
         x[j] = xj;
-        st->ng += 2;
-        for (int i = 0; i < n; ++i) H[(size_t)j * n + i] = (gp[i] - gm[i]) / (2.0 * h);
+        if (st) st->ng += 2;
+        const double w = 0.5 / h;
+        for (int i = 0; i < n; ++i) H[(size_t)j * n + i] = (gp[i] - gm[i]) * w;
     }
     free(gp);
+}
+static void central_hessian(flo_fd_t fd, double *H, double *x, int n, void *ctx, flo_stats *st)
+{
+    flo_central_hessian(fd, H, x, n, ctx, st);
 }
 
 /* p=-matmul(H,g), sequential in k (flang runtime matmul order) */

@@ -13,8 +13,8 @@
  * so no reference build is made.  The restatement is pinned against the
  * reference outputs recorded in BASELINE.md section 2 (final objective values
  * and f / grad evaluation counts measured on the reference during the survey);
- * see tests/test_oracle_pins.py.  Everything those numbers do not cover
- * (numerical-Hessian branches = MKL djacobi) is "parity unpinned".
+ * see tests/test_oracle_pins.py.  The numerical-Hessian branches call MKL's djacobi: its restatement here
+ * (flo_central_hessian) is pinned to the real routine's outputs (tests/golden/mkl_djacobi.npz).
  *
  * Two summation modes:
  *   FLO_SUM_SEQ  : every dot_product / objective sum runs left to right like
@@ -90,12 +90,13 @@ void flo_lbfgs(flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, double *x, int n, const f
                flo_stats *st); /* NO.f90:398 */
 /* BFGS (NO.f90:632).  update_form 0 = as written (two dense matmuls, NO.f90:961),
  * 1 = algebraically equal rank-2 form (what the HIP kernel computes). fdd may be NULL;
- * exact_step > 0 without fdd uses an own central difference (MKL djacobi: parity unpinned). */
+ * exact_step > 0 without fdd: central differences with djacobi's step rule (flo_central_hessian). */
 void flo_bfgs(flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, flo_fdd_t fdd, double *x, int n, const flo_opts *o,
               int update_form, void *ctx, flo_stats *st);
 /* NewtonRaphson with analytic Hessian (NO.f90:1026): Cholesky solve, steepest-descent fallback */
 void flo_newton(flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, flo_fdd_t fdd, double *x, int n, const flo_opts *o, void *ctx,
                 flo_stats *st);
+void flo_central_hessian(flo_fd_t fd, double *H, double *x, int n, void *ctx, flo_stats *st); /* MKL djacobi(fd_j,n,n,H,x,1d-8); st may be NULL */
 int flo_dposv_lower(double *A, double *b, int n); /* My_dposv LA.f90:719 : returns info, b untouched if it fails */
 int flo_dsysv(double *A, double *b, int n);       /* My_dsysv LA.f90:695 : symmetric indefinite (lower), elimination with partial pivoting */
 typedef int (*flo_cdd_t)(double *cddx, const double *x, int m, int n, void *ctx); /* c''(x): N x N x M */

@@ -177,11 +177,13 @@ int flo_solve_batch(int solver, int kind, int B, int n, double *x, const double 
             flo_conjugate_gradient(flo_prob_f, flo_prob_fd, ffd, xk, n, o, &P, &st);
         else if (solver == FLO_LBFGS)
             flo_lbfgs(flo_prob_f, flo_prob_fd, ffd, xk, n, o, &P, &st);
+        /* bfgs_form + 4096: the caller passes no fdd -- the reference then differentiates f' by MKL's djacobi
+         * (flo_central_hessian) where it wants a Hessian */
         else if (solver == 4 /* NewtonRaphson */)
-            flo_newton(flo_prob_f, flo_prob_fd, ffd, flo_prob_fdd, xk, n, o, &P, &st);
+            flo_newton(flo_prob_f, flo_prob_fd, ffd, (bfgs_form & 4096) ? NULL : flo_prob_fdd, xk, n, o, &P, &st);
         else
-            flo_bfgs(flo_prob_f, flo_prob_fd, ffd, o->exact_step > 0 ? flo_prob_fdd : NULL, xk, n, o, bfgs_form, &P,
-                     &st);
+            flo_bfgs(flo_prob_f, flo_prob_fd, ffd, (o->exact_step > 0 && !(bfgs_form & 4096)) ? flo_prob_fdd : NULL, xk, n, o,
+                     bfgs_form & 4095, &P, &st);
         if (fout) fout[k] = st.f;
         if (iters) iters[k] = st.iters;
         if (status) status[k] = st.status;

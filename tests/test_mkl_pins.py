@@ -63,6 +63,27 @@ def test_fl_djacobi_returns_the_bits_of_mkl_djacobi(name, fun, n):
     assert np.array_equal(np.ascontiguousarray(J).view(np.uint64), np.ascontiguousarray(Jmkl).view(np.uint64)), np.abs(J - Jmkl).max()
 
 
+@pytest.mark.parametrize("n", [10, 64])
+@pytest.mark.parametrize("name,fun", CASES)
+def test_oracle_central_hessian_returns_the_bits_of_mkl_djacobi(name, fun, n):
+    """the oracle's restatement of the djacobi call sites (oracle/fl_oracle.c: flo_central_hessian)"""
+    import oracle_lib as O
+    z = np.load(os.path.join(GOLD, "mkl_djacobi.npz"))
+    x, Jmkl = z[f"{name}_n{n}_x"], z[f"{name}_n{n}_J"]
+    fun = fun or G.make_grad_quadratic(n)
+    FD = C.CFUNCTYPE(None, dp, dp, C.c_int, C.c_void_p)
+
+    def cb(pg, px, nn, ctx):
+        g = fun(np.ctypeslib.as_array(px, (n,)).copy())
+        for i in range(n):
+            pg[i] = g[i]
+    H = np.zeros((n, n), order="F")
+    xc = x.copy()
+    O.lib().flo_central_hessian(FD(cb), H.ctypes.data_as(dp), xc.ctypes.data_as(dp), C.c_int(n), None, None)
+    assert np.array_equal(xc, x)
+    assert np.array_equal(np.ascontiguousarray(H).view(np.uint64), np.ascontiguousarray(Jmkl).view(np.uint64))
+
+
 def test_fl_djacobi_rejects_bad_arguments():
     lib = _lib()
     lib.fl_djacobi.restype = C.c_int

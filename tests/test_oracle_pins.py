@@ -2,7 +2,7 @@
 
 The reference ships no golden vectors (test/test.f90:33 seeds from the clock) and is not
 buildable in this image (NO.f90:15 includes Intel's closed mkl_rci.f90), so the only
-reference-produced numbers available are the survey's probe results: final objective
+reference-produced numbers available for the optimisers are the survey's probe results: final objective
 values printed with 17 significant digits and f / grad callback counts.  The probe
 drivers evaluated f once more after each solve to print it, hence "nf + 1" below.
 Inputs (from the survey's probe drivers): quartic x_i = 0.1 i; Rosenbrock standard start
@@ -47,6 +47,14 @@ def test_rosenbrock_n10_probes():
     r = O.solve_batch(O.BFGS, O.ROSENBROCK, x, opts=O.defaults(exact_step=0))
     assert r["f"][0] == 0.0 and np.all(r["x"] == 1.0)
     assert (r["nf"][0] + 1, r["ng"][0]) == (588, 446)
+    # BFGS with its DEFAULTS: ExactStep = 20 and no fdd, i.e. MKL's djacobi for f'' at the start and every 20 iterations
+    # (NO.f90:675-677, 979-981) + My_dpotri.  With djacobi's real step rule in the restatement (flo_central_hessian,
+    # pinned to the real routine by tests/golden/mkl_djacobi.npz) the probe's callback counts come out exactly --
+    # 2n of the 845 gradient calls per Hessian are djacobi's.  (bfgs_form + 4096: no fdd passed.)
+    for form in (4096, 4097):
+        r = O.solve_batch(O.BFGS, O.ROSENBROCK, x, opts=O.defaults(), bfgs_form=form)
+        assert r["f"][0] == 0.0 and np.all(r["x"] == 1.0)
+        assert (r["nf"][0] + 1, r["ng"][0]) == (844, 845)
     r = O.solve_batch(O.CG, O.ROSENBROCK, x, opts=O.defaults(c2=0.45))  # DY stalls
     assert _close(r["f"][0], 1.0269890190168409)
     assert abs(np.linalg.norm(r["x"] - 1) - 1.46) < 5e-3
