@@ -44,6 +44,7 @@ struct SolveArgs {
     double *lambda;         // [batch][aug_m] in/out
     int *outer;
     double *cnorm2;
+    const void *user; // a caller-compiled objective's own data (include/fl_user_objective.hpp); not read by the built-in ones
 };
 
 template <int NW, int EPT> struct Geo {
@@ -334,6 +335,22 @@ template <int NW, int EPT> struct Objective<FL_OBJ_EXTERNAL, NW, EPT> {
     }
 };
 
+// objective compiled in by the CALLER (include/fl_user_objective.hpp): a class template with the interface of the
+// specialisations above -- LDS_DOUBLES, init(), eval(), combine() -- named by the macro FL_USER_OBJECTIVE before this
+// header is included.  It gets the fused kernel, its geometry and its scheduling (wave priority, on-chip ring pairs, lazy
+// g.g), which the reverse-communication form (FL_OBJ_EXTERNAL) cannot have.
+#define FL_OBJ_USER 4
+#ifdef FL_USER_OBJECTIVE
+template <int NW, int EPT> struct Objective<FL_OBJ_USER, NW, EPT> : public FL_USER_OBJECTIVE<NW, EPT> {};
+#endif
+// whose register budget an objective's kernels are tuned like (occupancy caps, x0 in LDS, ...): the built-in ones like
+// themselves; a caller's objective like FL_USER_TUNE_LIKE -- by default like none of them (no caps: nothing can spill),
+// FL_OBJ_DIAGQUAD for an element-wise objective that keeps at most two data vectors in registers
+#ifndef FL_USER_TUNE_LIKE
+#define FL_USER_TUNE_LIKE FL_OBJ_USER
+#endif
+template <int OBJ> constexpr int tuned_like() { return OBJ == FL_OBJ_USER ? FL_USER_TUNE_LIKE : OBJ; }
+
 } // namespace fl
 #include "fl_dense.hpp"
 namespace fl {
@@ -415,7 +432,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
 #ifndef FL_AUG_LEAN18
 #define FL_AUG_LEAN18 1
 #endif
-    static constexpr bool AUG_LEAN18 = FL_AUG_LEAN18 && AUG && NW == 1 && EPT == 8 && OBJ == FL_OBJ_DIAGQUAD &&
+    static constexpr bool AUG_LEAN18 = FL_AUG_LEAN18 && AUG && NW == 1 && EPT == 8 && tuned_like<OBJ>() == FL_OBJ_DIAGQUAD &&
                                        (METHOD == FL_SOLVER_LBFGS || METHOD == FL_SOLVER_CG);
     static constexpr int LDS_PAIRS_WANT = (METHOD == FL_SOLVER_LBFGS && OBJ != FL_OBJ_EXTERNAL && !AUG_LEAN18) ? FL_LDS_PAIRS(NW, EPT) : 0;
     static constexpr int LDS_PAIRS = LDS_PAIRS_WANT < LDS_PAIRS_FIT ? LDS_PAIRS_WANT : LDS_PAIRS_FIT;
@@ -454,7 +471,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
 #define FL_X0_LDS 1
 #endif
     static constexpr bool X0_LDS = AUG_LEAN18 || (FL_X0_LDS && (METHOD == FL_SOLVER_SD || METHOD == FL_SOLVER_CG) && !AUG &&
-                                   OBJ == FL_OBJ_DIAGQUAD && EPT == 8 && NW >= 2); // (one wave per problem: 44 spills under the cap)
+                                   tuned_like<OBJ>() == FL_OBJ_DIAGQUAD && EPT == 8 && NW >= 2); // (one wave per problem: 44 spills under the cap)
     static constexpr int L_X0 = L_DEF + 2 * BF_DEFER;
     static constexpr int LDS_TOTAL = L_X0 + (X0_LDS ? NPAD : 0);
     using DN = Dense<NW, EPT>;

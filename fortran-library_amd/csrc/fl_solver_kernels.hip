@@ -167,46 +167,13 @@ static int solve(int method, int objective, int batch, int n, double *x, const d
         if (!select_big_geometry(n, g)) return FL_ERR_UNSUPPORTED_SIZE;
         big = true;
     }
-    SolveArgs A;
-    A.n = n;
-    A.batch = batch;
-    A.mem = opt->memory > 1 ? opt->memory : 1; // mem=max(1,Memory)
-    if (method == FL_SOLVER_LBFGS && A.mem > FL_MAX_MEMORY) return FL_ERR_UNSUPPORTED_SIZE;
+    const int mem = opt->memory > 1 ? opt->memory : 1; // mem=max(1,Memory)
+    if (method == FL_SOLVER_LBFGS && mem > FL_MAX_MEMORY) return FL_ERR_UNSUPPORTED_SIZE;
     if (method == FL_SOLVER_LBFGS || method == FL_SOLVER_BFGS || method == FL_SOLVER_NEWTON) {
         if (!ws || ws_bytes < fl_workspace_bytes_for(method, batch, n, opt)) return FL_ERR_WORKSPACE;
     }
-    A.exact_step = (method == FL_SOLVER_BFGS) ? opt->exact_step : 0;
-    A.maxit = opt->max_iteration;
-    A.strong = opt->strong != 0;
-    A.fused = opt->fused_f_fd != 0;
-    A.cg_method = opt->cg_method;
-    A.tol = opt->precision * opt->precision;                 // NO.f90:427
-    A.minstep = opt->min_step_length * opt->min_step_length; // NO.f90:429
-    A.c1 = opt->wolfe_c1;
-    A.c2 = opt->wolfe_c2;
-    if (opt->clamp) { // NO.f90:431-434
-        A.c1 = opt->wolfe_c1 > 1e-15 ? opt->wolfe_c1 : 1e-15;
-        const double lo = A.c1 + 1e-15;
-        const double c2 = opt->wolfe_c2 > lo ? opt->wolfe_c2 : lo;
-        A.c2 = c2 < 1.0 - 1e-15 ? c2 : 1.0 - 1e-15;
-    }
-    A.incr = opt->increment;
-    A.x = x;
-    A.d = d;
-    A.b = b;
-    A.hist = static_cast<double *>(ws);
-    A.f_out = f;
-    A.gg_out = gg;
-    A.iters = iters;
-    A.status = status;
-    A.nf = nf;
-    A.ng = ng;
-    A.aug_m = 0;
-    A.miu0 = 1.0;
-    A.precision = opt->precision;
-    A.lambda = nullptr;
-    A.outer = nullptr;
-    A.cnorm2 = nullptr;
+    SolveArgs A;
+    fill_solve_args(A, method, batch, n, x, d, b, opt, ws, f, gg, iters, status, nf, ng);
     if (aug) {
         if (aug->m < 1 || aug->m > FL_MAX_CONSTRAINTS || n % aug->m != 0 || !aug->lambda)
             return FL_ERR_INVALID_ARGUMENT;

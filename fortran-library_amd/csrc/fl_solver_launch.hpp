@@ -20,12 +20,12 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> constexpr int min_waves
     return FL_MIN_WPE;
 #else
     // (the quartic / Rosenbrock instances would spill 10-14 VGPRs under the cap: left alone)
-    if (AUG && EPT == 4 && NW <= 2 && OBJ == FL_OBJ_DIAGQUAD && (METHOD == FL_SOLVER_LBFGS || METHOD == FL_SOLVER_CG)) return 4;
-    if (FL_AUG_LEAN18 && AUG && EPT == 8 && NW == 1 && OBJ == FL_OBJ_DIAGQUAD && (METHOD == FL_SOLVER_LBFGS || METHOD == FL_SOLVER_CG)) return FL_AUG18_WPE; // Solver::AUG_LEAN18 (4 waves: 80-100 spills)
+    if (AUG && EPT == 4 && NW <= 2 && tuned_like<OBJ>() == FL_OBJ_DIAGQUAD && (METHOD == FL_SOLVER_LBFGS || METHOD == FL_SOLVER_CG)) return 4;
+    if (FL_AUG_LEAN18 && AUG && EPT == 8 && NW == 1 && tuned_like<OBJ>() == FL_OBJ_DIAGQUAD && (METHOD == FL_SOLVER_LBFGS || METHOD == FL_SOLVER_CG)) return FL_AUG18_WPE; // Solver::AUG_LEAN18 (4 waves: 80-100 spills)
     // SD / CG on them at 8 elements per thread, x0 in LDS (Solver::X0_LDS)
-    if (!AUG && OBJ == FL_OBJ_DIAGQUAD && EPT == 8 && NW >= 2 && (METHOD == FL_SOLVER_SD || METHOD == FL_SOLVER_CG) && FL_X0_LDS) return 4;
+    if (!AUG && tuned_like<OBJ>() == FL_OBJ_DIAGQUAD && EPT == 8 && NW >= 2 && (METHOD == FL_SOLVER_SD || METHOD == FL_SOLVER_CG) && FL_X0_LDS) return 4;
     // L-BFGS on them at 4 elements per thread (n <= 512): 134-135
-    if (!AUG && OBJ == FL_OBJ_DIAGQUAD && EPT == 4 && METHOD == FL_SOLVER_LBFGS) return 4;
+    if (!AUG && tuned_like<OBJ>() == FL_OBJ_DIAGQUAD && EPT == 4 && METHOD == FL_SOLVER_LBFGS) return 4;
     return 1;
 #endif
 }
@@ -75,6 +75,50 @@ void fl_solve_kernel(SolveArgs A)
         rq = s.advance(fv, pv, gg);
     }
     s.finish();
+}
+
+// the reference's optional arguments -> the kernel's arguments (defaults and clamps of NO.f90:419-434); shared by the
+// built-in entry points (fl_solver_kernels.hip) and a caller-compiled objective (include/fl_user_objective.hpp)
+static inline void fill_solve_args(SolveArgs &A, int method, int batch, int n, double *x, const double *d, const double *b,
+                                   const fl_options *opt, void *ws, double *f, double *gg, int32_t *iters, int32_t *status,
+                                   int32_t *nf, int32_t *ng)
+{
+    A.n = n;
+    A.batch = batch;
+    A.mem = opt->memory > 1 ? opt->memory : 1; // mem=max(1,Memory)
+    A.exact_step = (method == FL_SOLVER_BFGS) ? opt->exact_step : 0;
+    A.maxit = opt->max_iteration;
+    A.strong = opt->strong != 0;
+    A.fused = opt->fused_f_fd != 0;
+    A.cg_method = opt->cg_method;
+    A.tol = opt->precision * opt->precision;                 // NO.f90:427
+    A.minstep = opt->min_step_length * opt->min_step_length; // NO.f90:429
+    A.c1 = opt->wolfe_c1;
+    A.c2 = opt->wolfe_c2;
+    if (opt->clamp) { // NO.f90:431-434
+        A.c1 = opt->wolfe_c1 > 1e-15 ? opt->wolfe_c1 : 1e-15;
+        const double lo = A.c1 + 1e-15;
+        const double c2 = opt->wolfe_c2 > lo ? opt->wolfe_c2 : lo;
+        A.c2 = c2 < 1.0 - 1e-15 ? c2 : 1.0 - 1e-15;
+    }
+    A.incr = opt->increment;
+    A.x = x;
+    A.d = d;
+    A.b = b;
+    A.hist = static_cast<double *>(ws);
+    A.f_out = f;
+    A.gg_out = gg;
+    A.iters = iters;
+    A.status = status;
+    A.nf = nf;
+    A.ng = ng;
+    A.aug_m = 0;
+    A.miu0 = 1.0;
+    A.precision = opt->precision;
+    A.lambda = nullptr;
+    A.outer = nullptr;
+    A.cnorm2 = nullptr;
+    A.user = nullptr;
 }
 
 template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = 0>
