@@ -292,12 +292,32 @@ FL.fl_rci_results.argtypes = [_vp, _dp, _dp, _ip, _ip, _ip, _ip]
 FL.fl_rci_destroy.argtypes = [_vp]
 
 
-def minimize_rci(solver, x, fun, options=None, max_steps=10000000, check_every=8, **kw):
-    """Batched minimisation of a user objective by reverse communication (fl_rci_*): `fun(x)` returns
-    (f[batch], g[batch, n]) torch CUDA tensors for the whole batch; x is updated in place.  The solver
-    machines run in the HIP kernels; only the objective is the caller's.  solver: SD | CG | LBFGS_ | BFGS_.
-    The request vector is brought to the host only every `check_every` steps (a step on a finished batch is a
-    no-op on the device), and f, g are handed over without a copy when they are contiguous float64."""
+if hasattr(FL, "fl_rci_step_flags"):
+    FL.fl_rci_step_flags.argtypes = [_vp, _dp, _dp, _dp, _ip, C.c_int]
+    FL.fl_rci_step_compact.argtypes = [_vp, _dp, _ip, C.c_int, _dp, _dp, _dp, _ip, C.c_int]
+RCI_BOTH = 1
+
+
+def _f64c(t):
+    import torch
+    return t if (t.dtype == torch.float64 and t.is_contiguous()) else t.to(torch.float64).contiguous()
+
+
+def minimize_rci(solver, x, fun, options=None, max_steps=10000000, check_every=8, mode="legacy", compact_below=0.5, **kw):
+    """Batched minimisation of a user objective by reverse communication (fl_rci_*); x [batch, n] is updated in place.
+    The solver machines run in the HIP kernels; only the objective is the caller's.  solver: SD | CG | LBFGS_ | BFGS_.
+
+    mode="legacy": `fun(x)` returns (f[batch], g[batch, n]) for the whole batch on every step, and every request of the
+        reference's callback pattern -- f alone, then f' at the same point -- is a step of its own (fl_rci_step).
+    mode="full":   `fun(x, request)` as above, but f AND g are taken at every point (FL_RCI_BOTH): one step per distinct
+        trial point, like the fused kernels.  Finished problems cost one word per step on the device; the objective still
+        sees the whole batch (request[k] == 0 marks the rows it may skip).
+    mode="compact" (SD | CG | LBFGS_): `fun(xc, request, ids, epoch)` gets only the ACTIVE problems: xc [n_active, n], their
+        problem ids [n_active] and a counter that changes whenever the list does (so that per-problem data can be
+        gathered once per change, not per call); returns (f[n_active], g[n_active, n]).  The list is re-compacted when
+        fewer than `compact_below` of its problems are still running: the tail of the slowest problems costs
+        evaluations of those problems only.
+    The request vector is brought to the host only every `check_every` steps."""
     import torch
     o = options if options is not None else default_options(solver, **kw)
     B, n, out = _prep(x, None, None)
@@ -305,18 +325,41 @@ def minimize_rci(solver, x, fun, options=None, max_steps=10000000, check_every=8
     _check(FL.fl_rci_create(C.byref(h), solver, B, n, C.byref(o), _stream()), "fl_rci_create")
     try:
         req = torch.empty(B, dtype=torch.int32, device=x.device)
-        _check(FL.fl_rci_step(h, _ptr(x), None, None, _ptr(req)), "fl_rci_step")
         steps = 0
-        while steps < max_steps:
-            if steps % check_every == 0 and not bool((req != 0).any()):
-                break
-            fn, gn = fun(x)
-            if fn.dtype != torch.float64 or not fn.is_contiguous():
-                fn = fn.to(torch.float64).contiguous()
-            if gn.dtype != torch.float64 or not gn.is_contiguous():
-                gn = gn.to(torch.float64).contiguous()
-            _check(FL.fl_rci_step(h, _ptr(x), _ptr(fn), _ptr(gn), _ptr(req)), "fl_rci_step")
-            steps += 1
+        if mode == "compact":
+            ids = torch.arange(B, dtype=torch.int32, device=x.device)
+            xc = x.clone()
+            na, epoch = B, 0
+            _check(FL.fl_rci_step_compact(h, _ptr(x), _ptr(ids), na, _ptr(xc), None, None, _ptr(req), RCI_BOTH), "fl_rci_step_compact")
+            while steps < max_steps:
+                if steps % check_every == 0:
+                    running = int((req[:na] != 0).sum())
+                    if running == 0:
+                        break
+                    if running < compact_below * na:  # drop the finished problems from the list, moving their rows along
+                        keep = torch.nonzero(req[:na]).flatten()
+                        ids[:running] = ids[:na][keep]
+                        xc[:running] = xc[:na][keep]
+                        req[:running] = req[:na][keep]
+                        na, epoch = running, epoch + 1
+                fn, gn = fun(xc[:na], req[:na], ids[:na], epoch)
+                _check(FL.fl_rci_step_compact(h, _ptr(x), _ptr(ids), na, _ptr(xc), _ptr(_f64c(fn)), _ptr(_f64c(gn)), _ptr(req),
+                                              RCI_BOTH), "fl_rci_step_compact")
+                steps += 1
+        else:
+            if mode == "full":
+                def step(fp, gp):
+                    return FL.fl_rci_step_flags(h, _ptr(x), fp, gp, _ptr(req), RCI_BOTH)
+            else:
+                def step(fp, gp):
+                    return FL.fl_rci_step(h, _ptr(x), fp, gp, _ptr(req))
+            _check(step(None, None), "fl_rci_step")
+            while steps < max_steps:
+                if steps % check_every == 0 and not bool((req != 0).any()):
+                    break
+                fn, gn = fun(x, req) if mode == "full" else fun(x)
+                _check(step(_ptr(_f64c(fn)), _ptr(_f64c(gn))), "fl_rci_step")
+                steps += 1
         _check(FL.fl_rci_results(h, _ptr(out["f"]), _ptr(out["gg"]), _ptr(out["iters"]), _ptr(out["status"]),
                                  _ptr(out["nf"]), _ptr(out["ng"])), "fl_rci_results")
         torch.cuda.synchronize()

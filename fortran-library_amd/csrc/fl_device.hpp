@@ -493,6 +493,15 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
     double a_id;
     int hess_stage;       // reverse communication: where to resume once the caller has supplied the Hessian
     static constexpr bool HESS_RCI = (OBJ == FL_OBJ_EXTERNAL);
+    // Reverse communication, SD / CG / L-BFGS: of the parked rows [p, x0, g_old, g] a step moves only what it must.  p and
+    // x0 change when a line search BEGINS (stored then: ls_begun), g_old is written to and read from its HBM row directly
+    // where the machine uses it (g0_park() below), and g never has to survive a step: every line search ends on a
+    // gradient request, and the direction that uses that gradient is formed in the very step that takes it.  A trial
+    // step then loads x, p, x0 and the caller's g and stores the next trial point: 5 rows instead of 11.
+    static constexpr bool RCI_LAZY = (OBJ == FL_OBJ_EXTERNAL) && !AUG &&
+                                     (METHOD == FL_SOLVER_SD || METHOD == FL_SOLVER_CG || METHOD == FL_SOLVER_LBFGS);
+    double *rci_vec;      // this problem's parked rows (set by the step kernel before load())
+    bool ls_begun;        // a line search began in this step
     double yy_recent, rho_recent;
     LineSearch ls;
     // augmented Lagrangian
@@ -549,6 +558,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
     // buffer of the Cholesky kernels, which may run before g_old is wanted)
     __device__ __forceinline__ double *g0_park() const
     {
+        if constexpr (RCI_LAZY) return rci_vec + 2 * NPAD; // (its HBM row itself: touched only where a search begins / ends)
         if constexpr (METHOD == FL_SOLVER_BFGS) return lds + L_BF + NPAD;
         if constexpr (LDS_PAIRS > 0) {
             const int next = (lrec + 1 == LDS_PAIRS) ? 0 : lrec + 1;
@@ -609,10 +619,12 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
     }
 
     // ---------------------------------------------------------------- setup
-    __device__ __forceinline__ void init()
+    __device__ __forceinline__ void init(const double *xrow = nullptr) // xrow: where the current point lies (default x[prob][:])
     {
         obj.init(A, prob, lds + L_XS);
-        load_user<NW, EPT>(A.x + (size_t)prob * n, n, x);
+        load_user<NW, EPT>(xrow ? xrow : A.x + (size_t)prob * n, n, x);
+        rci_vec = nullptr;
+        ls_begun = false;
 #pragma unroll
         for (int k = 0; k < EPT; ++k) p[k] = 0.0;
         iters = nf = ng = 0;
@@ -1077,6 +1089,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
             for (int k = 0; k < EPT; ++k) x0[k] = x[k];
         }
         if constexpr (NEEDS_G0) store_pad<NW, EPT>(g0_park(), g); // fdold=fdnew, parked in LDS
+        ls_begun = true;
         phidold = phid;
         const int strong = (METHOD == FL_SOLVER_CG && A.cg_method == FL_CG_PR) ? 1 : A.strong;
         phase = PH_LS;
@@ -1932,13 +1945,20 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
     static constexpr int RCI_SCALARS = 48;
     __device__ __forceinline__ void save(double *sc, double *vec, double *rho, double fv_c, double pv_c)
     {
-        store_pad<NW, EPT>(vec, p);
-        store_pad<NW, EPT>(vec + NPAD, x0);
-        store_pad<NW, EPT>(vec + 3 * NPAD, g);
-        if constexpr (NEEDS_G0) {
-            double g0[EPT];
-            load_pad<NW, EPT>(g0_park(), g0);
-            store_pad<NW, EPT>(vec + 2 * NPAD, g0);
+        if constexpr (RCI_LAZY) {
+            if (ls_begun) { // (uniform) the only steps that change p and x0
+                store_pad<NW, EPT>(vec, p);
+                store_pad<NW, EPT>(vec + NPAD, x0);
+            }
+        } else {
+            store_pad<NW, EPT>(vec, p);
+            store_pad<NW, EPT>(vec + NPAD, x0);
+            store_pad<NW, EPT>(vec + 3 * NPAD, g);
+            if constexpr (NEEDS_G0) {
+                double g0[EPT];
+                load_pad<NW, EPT>(g0_park(), g0);
+                store_pad<NW, EPT>(vec + 2 * NPAD, g0);
+            }
         }
         if constexpr (METHOD == FL_SOLVER_LBFGS) {
             __syncthreads();
@@ -1975,11 +1995,13 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
     {
         load_pad<NW, EPT>(vec, p);
         load_pad<NW, EPT>(vec + NPAD, x0);
-        load_pad<NW, EPT>(vec + 3 * NPAD, g);
-        if constexpr (NEEDS_G0) {
-            double g0[EPT];
-            load_pad<NW, EPT>(vec + 2 * NPAD, g0);
-            store_pad<NW, EPT>(g0_park(), g0);
+        if constexpr (!RCI_LAZY) {
+            load_pad<NW, EPT>(vec + 3 * NPAD, g);
+            if constexpr (NEEDS_G0) {
+                double g0[EPT];
+                load_pad<NW, EPT>(vec + 2 * NPAD, g0);
+                store_pad<NW, EPT>(g0_park(), g0);
+            }
         }
         if constexpr (METHOD == FL_SOLVER_LBFGS) {
             if (threadIdx.x < FL_MAX_MEMORY) lds[L_RHO + threadIdx.x] = rho[threadIdx.x];

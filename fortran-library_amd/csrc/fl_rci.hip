@@ -28,61 +28,81 @@
 
 namespace fl {
 
+// flags of a step
+#define FL_RCI_BOTH 1 // the caller evaluated f AND grad f at every requested point, whatever the request bits said
+
+// One step of every (active) problem.  slot = blockIdx.x indexes the caller's arrays of this step (f, g, request, and the
+// points xio: the evaluated point in, the next requested point out); prob = active ? active[slot] : slot is the problem,
+// i.e. where its parked machine, its history and its final answer x[prob][:] live.  Without an active list the two
+// coincide and xio = x (the classic fl_rci_step).
 template <int NW, int EPT, int METHOD, int AUG = 0>
-__global__ __launch_bounds__(NW * 64) void rci_step_kernel(SolveArgs A, int first, double *sc_all, double *vec_all,
-                                                           double *rho_all, const double *f_dev,
-                                                           const double *g_dev, const double *c_dev,
-                                                           const double *cd_dev, int32_t *request)
+__global__ __launch_bounds__(NW * 64) void rci_step_kernel(SolveArgs A, int first, int flags, const int32_t *active, double *xio,
+                                                           double *sc_all, double *vec_all, double *rho_all, const double *f_dev,
+                                                           const double *g_dev, const double *c_dev, const double *cd_dev,
+                                                           int32_t *request)
 {
     using S = Solver<NW, EPT, FL_OBJ_EXTERNAL, METHOD, AUG>;
     __shared__ __attribute__((aligned(16))) double lds[S::LDS_TOTAL];
-    S s(A, lds);
-    const int prob = blockIdx.x, n = A.n;
+    const int slot = blockIdx.x, n = A.n;
+    const int prob = active ? active[slot] : slot;
     double *sc = sc_all + (size_t)prob * S::RCI_SCALARS;
     double *vec = vec_all + (size_t)prob * 4 * S::NPAD;
     double *rho = rho_all + (size_t)prob * FL_MAX_MEMORY;
-    s.init(); // x = the point the caller has just evaluated (or the initial guess)
+    // a finished problem costs nothing but this look at its parked phase (every thread reads the same word; thread 0
+    // alone rewrites the scalar block, and only after load()'s barrier: see the ownership rules above Solver::save)
+    if (!first && reinterpret_cast<const int *>(sc + 32)[4] == S::PH_DONE) {
+        if (threadIdx.x == 0) request[slot] = 0;
+        return;
+    }
+    S s(A, lds);
+    s.prob = prob;
+    double *xrow = xio + (size_t)slot * n;
+    s.init(xrow); // x = the point the caller has just evaluated (or the initial guess)
+    s.rci_vec = vec;
     int rq;
     double fv = 0.0, pv = 0.0;
     if (first) {
         rq = s.start();
     } else {
         s.load(sc, vec, rho, fv, pv);
-        if (s.phase == S::PH_DONE) {
-            if (threadIdx.x == 0) request[prob] = 0;
-            return;
-        }
         double ggv = s.gg;
-        const bool have_f = (s.pending & FL_REQ_F) && f_dev, have_g = (s.pending & FL_REQ_G) && g_dev;
+        const bool both = (flags & FL_RCI_BOTH) != 0;
+        const bool have_f = ((s.pending & FL_REQ_F) || both) && f_dev, have_g = ((s.pending & FL_REQ_G) || both) && g_dev;
         if constexpr (AUG) {
             // the caller's f, grad f, c, cd -> the augmented Lagrangian and its gradient (c comes with every request,
             // cd with every gradient request: the request bits FL_REQ_C / FL_REQ_CD say so)
-            if (have_g) load_user<NW, EPT>(g_dev + (size_t)prob * n, n, s.g);
-            s.take_external_aug(have_f ? f_dev[prob] : 0.0, have_f, have_g, c_dev + (size_t)prob * A.aug_m,
-                                cd_dev + (size_t)prob * A.aug_m * n, fv, pv, ggv);
+            if (have_g) load_user<NW, EPT>(g_dev + (size_t)slot * n, n, s.g);
+            s.take_external_aug(have_f ? f_dev[slot] : 0.0, have_f, have_g, c_dev + (size_t)slot * A.aug_m,
+                                cd_dev + (size_t)slot * A.aug_m * n, fv, pv, ggv);
         } else {
-            if (have_f) fv = f_dev[prob];
+            if (have_f) fv = f_dev[slot];
             if (have_g) {
-                load_user<NW, EPT>(g_dev + (size_t)prob * n, n, s.g);
+                load_user<NW, EPT>(g_dev + (size_t)slot * n, n, s.g);
                 double q[2] = {dot_part<EPT>(s.g, s.p), dot_part<EPT>(s.g, s.g)};
                 s.R.run(q);
                 pv = q[0];
                 ggv = q[1];
             }
         }
-        rq = s.advance(fv, pv, ggv);
+        // FL_RCI_BOTH: a request for the other quantity AT THE SAME POINT (StrongWolfe: f, then f' once Armijo holds,
+        // NO.f90:1483-1485) is answered on the spot instead of costing the caller another round
+        bool again;
+        do {
+            rq = s.advance(fv, pv, ggv);
+            again = both && !AUG && rq != 0 && (rq & FL_REQ_SAME) && !(rq & FL_REQ_H);
+        } while (again);
     }
     if (rq == 0) {
         s.finish();
     } else if (!(rq & (FL_REQ_SAME | FL_REQ_NOMOVE))) {
         s.move(s.request_point());
-        store_user<NW, EPT>(A.x + (size_t)prob * n, n, s.x);
+        store_user<NW, EPT>(xrow, n, s.x);
     }
     s.save(sc, vec, rho, fv, pv);
     if (threadIdx.x == 0) {
         int out = rq;
         if (AUG && rq != 0) out |= FL_REQ_C | ((rq & FL_REQ_G) ? FL_REQ_CD : 0);
-        request[prob] = out;
+        request[slot] = out;
     }
 }
 
@@ -197,15 +217,16 @@ struct Rci {
 };
 
 template <int NW, int EPT>
-static void launch_rci(Rci *h, const double *f, const double *g, const double *c, const double *cd, int32_t *req)
+static void launch_rci(Rci *h, const double *f, const double *g, const double *c, const double *cd, int32_t *req, int flags,
+                       const int32_t *active, int nactive, double *xio)
 {
-    dim3 grid(h->batch), block(NW * 64);
-#define FL_RCI(M)                                                                                                 \
-    hipLaunchKernelGGL((rci_step_kernel<NW, EPT, M, 0>), grid, block, 0, h->stream, h->A, h->first, h->sc, h->vec, \
-                       h->rho, f, g, c, cd, req)
-#define FL_RCI_AUG(M)                                                                                             \
-    hipLaunchKernelGGL((rci_step_kernel<NW, EPT, M, 1>), grid, block, 0, h->stream, h->A, h->first, h->sc, h->vec, \
-                       h->rho, f, g, c, cd, req)
+    dim3 grid(active ? nactive : h->batch), block(NW * 64);
+#define FL_RCI(M)                                                                                                     \
+    hipLaunchKernelGGL((rci_step_kernel<NW, EPT, M, 0>), grid, block, 0, h->stream, h->A, h->first, flags, active, xio, h->sc, \
+                       h->vec, h->rho, f, g, c, cd, req)
+#define FL_RCI_AUG(M)                                                                                                 \
+    hipLaunchKernelGGL((rci_step_kernel<NW, EPT, M, 1>), grid, block, 0, h->stream, h->A, h->first, flags, active, xio, h->sc, \
+                       h->vec, h->rho, f, g, c, cd, req)
     if (h->aug) { // AugmentedLagrangian around L-BFGS (NO.f90:2150-2167), ConjugateGradient (2168-2185) or quasi-Newton
                   // BFGS (2131-2148 with ExactStep <= 0: every outer round rebuilds H from a I)
         if (h->solver == FL_SOLVER_CG) FL_RCI_AUG(FL_SOLVER_CG);
@@ -338,24 +359,53 @@ int fl_rci_create(fl_rci **out, int solver, int batch, int n, const fl_options *
 }
 
 static int rci_step_any(fl_rci *h, double *x_dev, const double *f_dev, const double *g_dev, const double *c_dev,
-                        const double *cd_dev, int32_t *request_dev)
+                        const double *cd_dev, int32_t *request_dev, int flags = 0, const int32_t *active_dev = nullptr,
+                        int nactive = 0, double *xc_dev = nullptr)
 {
     if (!h || !x_dev || !request_dev) return FL_ERR_INVALID_ARGUMENT;
     if (h->r.aug && !h->r.first && (!c_dev || !cd_dev)) return FL_ERR_INVALID_ARGUMENT;
-    // f_dev / g_dev may be NULL on a step where no problem asked for them (the first step; a step that only delivers
-    // Hessians, FL_REQ_H): the kernels read an array only for the problems whose request bit names it
     fl::Rci *r = &h->r;
+    // f_dev / g_dev may be NULL only where no problem can have asked for them: on the first step, and with a solver that
+    // takes Hessians from the caller (a step that only delivers them, FL_REQ_H); otherwise a NULL array is a caller's bug,
+    // not something to step the machines past
+    const bool hessians = r->solver == FL_SOLVER_NEWTON || (r->solver == FL_SOLVER_BFGS && r->A.exact_step > 0);
+    if (!r->first && !hessians && (!f_dev || !g_dev)) return FL_ERR_INVALID_ARGUMENT;
     r->A.x = x_dev;
     const int nw = r->nw, ept = r->ept;
-    if (nw == 16) fl::launch_rci_big(r, f_dev, g_dev, request_dev);
-    else if (nw == 1 && ept == 2) fl::launch_rci<1, 2>(r, f_dev, g_dev, c_dev, cd_dev, request_dev);
-    else if (nw == 1 && ept == 4) fl::launch_rci<1, 4>(r, f_dev, g_dev, c_dev, cd_dev, request_dev);
-    else if (nw == 1 && ept == 8) fl::launch_rci<1, 8>(r, f_dev, g_dev, c_dev, cd_dev, request_dev);
-    else if (nw == 2 && ept == 8) fl::launch_rci<2, 8>(r, f_dev, g_dev, c_dev, cd_dev, request_dev);
-    else if (nw == 4 && ept == 8) fl::launch_rci<4, 8>(r, f_dev, g_dev, c_dev, cd_dev, request_dev);
-    else fl::launch_rci<8, 8>(r, f_dev, g_dev, c_dev, cd_dev, request_dev);
+    double *xio = xc_dev ? xc_dev : x_dev;
+    if (nw == 16) {
+        if (active_dev || flags) return FL_ERR_UNSUPPORTED_SIZE; // (the vectors-in-HBM path steps whole batches)
+        fl::launch_rci_big(r, f_dev, g_dev, request_dev);
+    }
+    else if (nw == 1 && ept == 2) fl::launch_rci<1, 2>(r, f_dev, g_dev, c_dev, cd_dev, request_dev, flags, active_dev, nactive, xio);
+    else if (nw == 1 && ept == 4) fl::launch_rci<1, 4>(r, f_dev, g_dev, c_dev, cd_dev, request_dev, flags, active_dev, nactive, xio);
+    else if (nw == 1 && ept == 8) fl::launch_rci<1, 8>(r, f_dev, g_dev, c_dev, cd_dev, request_dev, flags, active_dev, nactive, xio);
+    else if (nw == 2 && ept == 8) fl::launch_rci<2, 8>(r, f_dev, g_dev, c_dev, cd_dev, request_dev, flags, active_dev, nactive, xio);
+    else if (nw == 4 && ept == 8) fl::launch_rci<4, 8>(r, f_dev, g_dev, c_dev, cd_dev, request_dev, flags, active_dev, nactive, xio);
+    else fl::launch_rci<8, 8>(r, f_dev, g_dev, c_dev, cd_dev, request_dev, flags, active_dev, nactive, xio);
     r->first = 0;
     return fl::launch_status();
+}
+
+// The step for a caller that compacts: only the n_active problems listed in active_dev are stepped, and the arrays of
+// the step -- xc_dev [n_active][n] (in: the points just evaluated; out: the next requested points), f_dev, g_dev,
+// request_dev -- are indexed by the position in that list.  x_dev [batch][n] receives a problem's minimiser when it
+// finishes.  Between two calls the caller may drop finished problems from the list, moving the rows of xc_dev along.
+int fl_rci_step_compact(fl_rci *h, double *x_dev, const int32_t *active_dev, int n_active, double *xc_dev, const double *f_dev,
+                        const double *g_dev, int32_t *request_dev, int flags)
+{
+    if (!h || !active_dev || !xc_dev || n_active <= 0 || n_active > h->r.batch) return FL_ERR_INVALID_ARGUMENT;
+    if (h->r.aug || (h->r.solver != FL_SOLVER_SD && h->r.solver != FL_SOLVER_CG && h->r.solver != FL_SOLVER_LBFGS))
+        return FL_ERR_INVALID_ARGUMENT; // (the dense solvers park their iterate in x_dev[prob]: whole-batch steps only)
+    if (flags & ~FL_RCI_BOTH) return FL_ERR_INVALID_ARGUMENT;
+    return rci_step_any(h, x_dev, f_dev, g_dev, nullptr, nullptr, request_dev, flags, active_dev, n_active, xc_dev);
+}
+
+int fl_rci_step_flags(fl_rci *h, double *x_dev, const double *f_dev, const double *g_dev, int32_t *request_dev, int flags)
+{
+    if (h && h->r.aug) return FL_ERR_INVALID_ARGUMENT;
+    if (flags & ~FL_RCI_BOTH) return FL_ERR_INVALID_ARGUMENT;
+    return rci_step_any(h, x_dev, f_dev, g_dev, nullptr, nullptr, request_dev, flags);
 }
 
 int fl_rci_step(fl_rci *h, double *x_dev, const double *f_dev, const double *g_dev, int32_t *request_dev)

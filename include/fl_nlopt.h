@@ -249,7 +249,8 @@ int fl_augmented_lagrangian_batched(int solver, int objective, int batch, int n,
  *        (x_dev holds its minimiser and is no longer touched).
  * The bits are exactly the reference's callback pattern (f only while Armijo fails, f' only once it
  * holds, f_fd when both are set and opt->fused_f_fd is on), so wrapping host callbacks reproduces the
- * reference's evaluation counts.  First call: x_dev = initial guesses, f_dev/g_dev may be NULL.
+ * reference's evaluation counts.  First call: x_dev = initial guesses, f_dev/g_dev may be NULL (afterwards only with a
+ * solver that takes Hessians, on a step that delivers nothing else; otherwise FL_ERR_INVALID_ARGUMENT).
  * Arrays whose bit was not requested are not read.  solver: FL_SOLVER_SD | CG | LBFGS | BFGS
  * (BFGS: ExactStep <= 0 path).  The handle owns its device buffers (history ring / inverse Hessians,
  * parked machine state).
@@ -261,6 +262,22 @@ typedef struct fl_rci fl_rci;
 int fl_rci_create(fl_rci **handle, int solver, int batch, int n, const fl_options *opt, void *stream);
 int fl_rci_hessian_buffer(fl_rci *handle, double **hessian_dev, int *ld);
 int fl_rci_step(fl_rci *handle, double *x_dev, const double *f_dev, const double *g_dev, int32_t *request_dev);
+/* The same step with flags.  FL_RCI_BOTH: the caller evaluated f AND grad f at every requested point, whatever the bits
+ * asked for (the natural form of a torch / HIP objective, the reference's f_fd).  The kernel then answers a request for the
+ * other quantity at the SAME point (bit 2: StrongWolfe asks for f, then for f' once Armijo holds, NO.f90:1483-1485) by
+ * itself instead of handing it back, so the caller sees one round per distinct trial point -- like the fused kernels --
+ * and the reference's evaluation counts (nf, ng) stay what they were. */
+#define FL_RCI_BOTH 1
+int fl_rci_step_flags(fl_rci *handle, double *x_dev, const double *f_dev, const double *g_dev, int32_t *request_dev, int flags);
+/* The step for a caller that COMPACTS (FL_SOLVER_SD | CG | LBFGS): only the n_active problems listed in active_dev
+ * [n_active] (problem ids, any order) are stepped, and the arrays of the step -- xc_dev [n_active][n] (in: the points just
+ * evaluated, out: the next requested points), f_dev [n_active], g_dev [n_active][n], request_dev [n_active] -- are indexed
+ * by the position in that list.  x_dev [batch][n] receives a problem's minimiser when it finishes (request 0).  Between
+ * two calls the caller may drop finished problems from the list, moving the rows of xc_dev along; the tail of a batch
+ * -- a few slow problems -- then costs evaluations of those problems only.  First call: every problem listed, xc_dev =
+ * the initial guesses.  A finished problem that is still listed costs one word read. */
+int fl_rci_step_compact(fl_rci *handle, double *x_dev, const int32_t *active_dev, int n_active, double *xc_dev,
+                        const double *f_dev, const double *g_dev, int32_t *request_dev, int flags);
 /* copies the per-problem outputs (device pointers, each may be NULL) after all requests are 0 */
 int fl_rci_results(fl_rci *handle, double *f_dev, double *gg_dev, int32_t *iters_dev, int32_t *status_dev,
                    int32_t *nf_dev, int32_t *ng_dev);

@@ -203,6 +203,50 @@ def test_rci_batched_torch_objective_equals_fused_kernel():
         assert torch.allclose(out["f"], ref["f"], rtol=1e-10, atol=0)
 
 
+@pytest.mark.parametrize("solver_name", ["LBFGS", "CG", "SD"])
+def test_rci_full_and_compact_modes_walk_the_same_path_in_fewer_rounds(solver_name):
+    """fl_rci_step_flags(FL_RCI_BOTH) answers same-point requests inside the kernel, fl_rci_step_compact steps only the
+    listed problems with the step's arrays in list order: same minimisers, iteration and evaluation COUNTS (the
+    reference's callback pattern) as the classic one-request-per-step loop, bit for bit -- in fewer rounds, and the
+    objective sees only running problems once the batch thins out (ragged iteration counts: kappa from 2 to 1e4)."""
+    import FortranLibrary.NonlinearOptimization as NLO
+    dev = torch.device("cuda:0")
+    B, n = 96, 200
+    rng = np.random.default_rng(3)
+    kappa = np.exp(rng.uniform(np.log(2), np.log(1e4), B))
+    d = torch.tensor(1.0 + (kappa[:, None] - 1.0) * (np.arange(n) / (n - 1))[None, :], device=dev)
+    b = torch.tensor(rng.uniform(-1, 1, (B, n)), device=dev)
+    solver = {"LBFGS": NLO.LBFGS_, "CG": NLO.CG, "SD": NLO.SD}[solver_name]
+    kw = dict(Precision=1e-6, MaxIteration=150 if solver_name == "SD" else 1000)
+    seen = {"rows": 0, "calls": 0, "epochs": set()}
+    cache = {}
+
+    def f_of(xx, dd, bb):
+        dx = dd * xx
+        return 0.5 * (dx * xx).sum(1) - (bb * xx).sum(1), dx - bb
+
+    def fun_compact(xc, req, ids, epoch):
+        if cache.get("epoch") != epoch:  # gather the problems' data once per change of the list
+            i = ids.long()
+            cache.update(epoch=epoch, d=d[i], b=b[i])
+        seen["rows"] += xc.shape[0]
+        seen["calls"] += 1
+        seen["epochs"].add(epoch)
+        return f_of(xc, cache["d"], cache["b"])
+    xa = torch.zeros(B, n, dtype=torch.float64, device=dev)
+    a = NLO.minimize_rci(solver, xa, lambda xx: f_of(xx, d, b), **kw)
+    xf = torch.zeros(B, n, dtype=torch.float64, device=dev)
+    f = NLO.minimize_rci(solver, xf, lambda xx, rq: f_of(xx, d, b), mode="full", **kw)
+    xc = torch.zeros(B, n, dtype=torch.float64, device=dev)
+    c = NLO.minimize_rci(solver, xc, fun_compact, mode="compact", check_every=4, **kw)
+    for o, xx in ((f, xf), (c, xc)):
+        assert torch.equal(xx, xa)
+        for k in ("f", "gg", "iters", "status", "nf", "ng"):
+            assert torch.equal(o[k], a[k]), k
+    assert f["steps"] < a["steps"] and c["steps"] <= f["steps"]  # (steps are counted up to the next look at the requests)
+    assert len(seen["epochs"]) > 1 and seen["rows"] < 0.8 * B * c["steps"]  # the tail is evaluated for the running problems only
+
+
 def test_fortran_use_fortranlibrary_smoke():
     """`use FortranLibrary` from Fortran (amdflang): the shim module forwards to libFL.so, the solver runs on the
     GPU and calls the Fortran callbacks on the host.  Mirrors test/test.f90:330-413: residuals close to 0."""

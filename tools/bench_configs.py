@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--c4-batch", type=int, default=1024)
     ap.add_argument("--c4-iterations", type=int, default=20)
     ap.add_argument("--c5-batch", type=int, default=8192)
+    ap.add_argument("--rci-batch", type=int, default=16384)
+    ap.add_argument("--rci-modes", default="legacy,full,compact")
     args = ap.parse_args()
     global REPS
     REPS = args.reps
@@ -374,6 +376,56 @@ def main():
             print(json.dumps({"config": f"dense BFGS (ExactStep=0) beyond the register path: quadratics n={n}, batch {B}, {K} iterations",
                               "ms": ms, "iterations_per_s": float(it.sum()) / ms * 1e3, "iterations": int(it.sum()),
                               "moved_GBps_model": moved / ms / 1e6, "inverse_hessian_bytes": B * n * n * 8}))
+
+    if "rci" in args.configs:  # the generic-objective path: the headline workload through reverse communication, torch objective
+        B, n, m = args.rci_batch, 1024, 10
+        d, b = quad(B, n, 10.0, 1000.0)
+        x = torch.zeros(B, n, dtype=torch.float64, device=dev)
+        ws = NLO.workspace(B, n, m, dev)
+        kw = dict(Precision=1e-6, MaxIteration=3000, Memory=m)
+
+        def fused():
+            x.zero_()
+            return NLO.LBFGS(NLO.DIAGQUAD, x, d, b, workspace_=ws, **kw)
+        outf, msf = timed(fused, 3)
+        xf = x.clone()
+        calls = {"n": 0, "rows": 0}
+        cache = {}
+
+        def f_of(xx, dd, bb):
+            dx = dd * xx
+            return 0.5 * (dx * xx).sum(1) - (bb * xx).sum(1), dx - bb
+
+        def fun(xx, req=None, ids=None, epoch=None):
+            calls["n"] += 1
+            calls["rows"] += xx.shape[0]
+            if ids is None:
+                return f_of(xx, d, b)
+            if cache.get("epoch") != epoch:  # the list of running problems changed: gather their data once
+                i = ids.long()
+                cache.update(epoch=epoch, d=d[i], b=b[i])
+            return f_of(xx, cache["d"], cache["b"])
+        first = None
+        for mode in args.rci_modes.split(","):
+            x.zero_()
+            calls.update(n=0, rows=0)
+            cache.clear()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            out = NLO.minimize_rci(NLO.LBFGS_, x, fun, mode=mode, **kw)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t
+            it = int(out["iters"].to(torch.int64).sum())
+            if first is None:
+                first = (x.clone(), out["iters"].clone(), out["nf"].clone())
+            print(json.dumps({"config": f"RCI ({mode}) L-BFGS m=10, diagonal quadratics n=1024, batch {B}, torch objective", "ms": dt * 1e3,
+                              "iterations_per_s": it / dt, "iterations": it, "steps": out["steps"], "objective_calls": calls["n"],
+                              "objective_rows_evaluated": calls["rows"], "trials": int(out["nf"].to(torch.int64).sum()),
+                              "rows_per_trial": calls["rows"] / max(1, int(out["nf"].to(torch.int64).sum())),
+                              "fused_kernel_ms": msf, "fused_iterations_per_s": float(outf["iters"].to(torch.int64).sum()) / msf * 1e3,
+                              "same_bits_as_the_first_mode": bool(torch.equal(x, first[0]) and torch.equal(out["iters"], first[1]) and torch.equal(out["nf"], first[2])),
+                              "max_rel_x_diff_vs_fused": float(((x - xf).norm(dim=1) / xf.norm(dim=1)).max()),
+                              "slowdown_vs_fused": dt * 1e3 / msf}))
 
     if "c5" in args.configs:  # aug-Lagrangian wrapping L-BFGS, batch 8192 n=512, 8 equality constraints
         B, n, M, m = args.c5_batch, 512, 8, 10
