@@ -493,3 +493,32 @@ def synth_diag_spectrum(seed, out, kappa_lo, kappa_hi):
     B, n = out.shape
     _check(FL.fl_synth_diag_spectrum(seed, B, n, kappa_lo, kappa_hi, _ptr(out), _stream()),
            "fl_synth_diag_spectrum")
+
+
+def multi_solve(solver, objective, x, d=None, b=None, M=0, lambda0=None, miu0=1.0, nshards=0, interleaved=False, options=None, **kw):
+    """A batch of independent problems over all the GPUs of the node from this one process (fl_multi_solve): numpy HOST
+    arrays [batch, n] in, x updated in place, one host thread per shard.  M > 0: AugmentedLagrangian with M block-sphere
+    constraints around `solver`.  nshards = 0: one shard per visible device.  Returns the usual per-problem outputs."""
+    import numpy as np
+    o = options if options is not None else default_options(solver, **kw)
+    if not (isinstance(x, np.ndarray) and x.dtype == np.float64 and x.ndim == 2 and x.flags.c_contiguous):
+        raise ValueError("x must be a C-contiguous float64 numpy array [batch, n]")
+    B, n = x.shape
+    dd = None if d is None else np.ascontiguousarray(d, dtype=np.float64)
+    bb = None if b is None else np.ascontiguousarray(b, dtype=np.float64)
+    out = dict(f=np.zeros(B), gg=np.zeros(B), iters=np.zeros(B, np.int32), status=np.zeros(B, np.int32),
+               nf=np.zeros(B, np.int32), ng=np.zeros(B, np.int32))
+    lam = cn = outer = None
+    if M:
+        lam = np.zeros((B, M)) if lambda0 is None else np.ascontiguousarray(lambda0, dtype=np.float64).copy()
+        cn, outer = np.zeros(B), np.zeros(B, np.int32)
+        out.update({"lambda": lam, "cnorm2": cn, "outer": outer})
+
+    def p(a):
+        return a.ctypes.data_as(C.c_void_p) if a is not None else None
+    FL.fl_multi_solve.argtypes = [C.c_int] * 4 + [C.c_void_p] * 3 + [C.POINTER(Options), C.c_int, C.c_void_p, C.c_double] + \
+        [C.c_void_p] * 8 + [C.c_int, C.c_int]
+    _check(FL.fl_multi_solve(solver, objective, B, n, p(x), p(dd), p(bb), C.byref(o), M, p(lam), float(miu0), p(out["f"]),
+                             p(out["gg"]), p(cn), p(out["iters"]), p(outer), p(out["status"]), p(out["nf"]), p(out["ng"]),
+                             int(nshards), int(bool(interleaved))), "fl_multi_solve")
+    return out

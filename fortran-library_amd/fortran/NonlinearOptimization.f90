@@ -151,6 +151,19 @@ module NonlinearOptimization
             type(c_ptr),value::x,d,b,f,gg,iters,status,nf,ng,stream
             type(fl_options),intent(in)::opt
         end function fl_conjugate_gradient_batched
+        !A batch of independent problems over all the GPUs of the node: host arrays x(n,batch), d(n,batch), b(n,batch) in,
+        !results out, one host thread per shard (include/fl_nlopt.h: fl_multi_solve).  Absent outputs: c_null_ptr.
+        integer(c_int) function fl_multi_device_count() bind(C,name='fl_multi_device_count')
+            import
+        end function fl_multi_device_count
+        integer(c_int) function fl_multi_solve(solver,objective,batch,n,x,d,b,opt,aug_m,lambda,miu0,f,gg,cnorm2,iters,outer,&
+        status,nf,ng,nshards,interleaved) bind(C,name='fl_multi_solve')
+            import
+            integer(c_int),value::solver,objective,batch,n,aug_m,nshards,interleaved
+            type(c_ptr),value::x,d,b,lambda,f,gg,cnorm2,iters,outer,status,nf,ng!HOST pointers (c_loc of the arrays)
+            type(fl_options),intent(in)::opt
+            real(c_double),value::miu0
+        end function fl_multi_solve
     end interface
 
 contains

@@ -237,6 +237,22 @@ int fl_augmented_lagrangian_batched(int solver, int objective, int batch, int n,
                                     double *cnorm2_dev, int32_t *iters_dev, int32_t *outer_dev, int32_t *status_dev,
                                     int32_t *nf_dev, int32_t *ng_dev, void *stream);
 
+/* ---- all the GPUs of the node from one process --------------------------------------------------
+ * The batched solvers above for HOST arrays, sharded over the visible devices by one host thread per shard (hipSetDevice,
+ * upload, one launch of the fused kernel on the shard's own stream, the shard's rows of the results written straight
+ * into the caller's arrays).  Problems are independent: no collective, no exchange beyond that write-back.
+ *   solver     FL_SOLVER_SD | CG | LBFGS | BFGS | NEWTON;  objective, opt, outputs: as in the one-device entries
+ *   aug_m > 0  AugmentedLagrangian around `solver` with aug_m block-sphere constraints (fl_augmented_lagrangian_batched):
+ *              lambda_host [batch][aug_m] in (NULL: lambda0 = 0) / out, miu0, cnorm2_host, outer_host; gg_host unused
+ *   nshards    <= 0: one shard per visible device; more shards than devices share devices round-robin
+ *   interleaved  0: contiguous blocks of ceil(batch / nshards) problems;  1: problem k -> shard k mod nshards
+ * Every output pointer may be NULL.  Results do not depend on the sharding (one workgroup owns one problem either way). */
+int fl_multi_device_count(void);
+int fl_multi_solve(int solver, int objective, int batch, int n, double *x_host, const double *d_host, const double *b_host,
+                   const fl_options *opt, int aug_m, double *lambda_host, double miu0, double *f_host, double *gg_host,
+                   double *cnorm2_host, int32_t *iters_host, int32_t *outer_host, int32_t *status_host, int32_t *nf_host,
+                   int32_t *ng_host, int nshards, int interleaved);
+
 /* ---- reverse communication: objectives evaluated by the caller -------------------------------
  * The reference calls back into user code for every evaluation (subroutine f(fx,x,dim), fd(g,x,dim),
  * integer function f_fd(fx,g,x,dim): NO.f90:33-38).  For a batch on the GPU the same protocol is an
