@@ -86,11 +86,16 @@ __global__ __launch_bounds__(NW * 64) void rci_step_kernel(SolveArgs A, int firs
         }
         // FL_RCI_BOTH: a request for the other quantity AT THE SAME POINT (StrongWolfe: f, then f' once Armijo holds,
         // NO.f90:1483-1485) is answered on the spot instead of costing the caller another round
-        bool again;
-        do {
+        // (SD / CG / L-BFGS; the dense solvers' kernels have no registers to spare for a loop around the machine)
+        if constexpr (S::RCI_LAZY) {
+            bool again;
+            do {
+                rq = s.advance(fv, pv, ggv);
+                again = both && rq != 0 && (rq & FL_REQ_SAME);
+            } while (again);
+        } else {
             rq = s.advance(fv, pv, ggv);
-            again = both && !AUG && rq != 0 && (rq & FL_REQ_SAME) && !(rq & FL_REQ_H);
-        } while (again);
+        }
     }
     if (rq == 0) {
         s.finish();
@@ -405,6 +410,8 @@ int fl_rci_step_flags(fl_rci *h, double *x_dev, const double *f_dev, const doubl
 {
     if (h && h->r.aug) return FL_ERR_INVALID_ARGUMENT;
     if (flags & ~FL_RCI_BOTH) return FL_ERR_INVALID_ARGUMENT;
+    if (flags && h && h->r.solver != FL_SOLVER_SD && h->r.solver != FL_SOLVER_CG && h->r.solver != FL_SOLVER_LBFGS)
+        return FL_ERR_INVALID_ARGUMENT; // FL_RCI_BOTH: the vector solvers (the dense ones step request by request)
     return rci_step_any(h, x_dev, f_dev, g_dev, nullptr, nullptr, request_dev, flags);
 }
 

@@ -278,7 +278,7 @@ typedef struct fl_rci fl_rci;
 int fl_rci_create(fl_rci **handle, int solver, int batch, int n, const fl_options *opt, void *stream);
 int fl_rci_hessian_buffer(fl_rci *handle, double **hessian_dev, int *ld);
 int fl_rci_step(fl_rci *handle, double *x_dev, const double *f_dev, const double *g_dev, int32_t *request_dev);
-/* The same step with flags.  FL_RCI_BOTH: the caller evaluated f AND grad f at every requested point, whatever the bits
+/* The same step with flags (FL_SOLVER_SD | CG | LBFGS).  FL_RCI_BOTH: the caller evaluated f AND grad f at every requested point, whatever the bits
  * asked for (the natural form of a torch / HIP objective, the reference's f_fd).  The kernel then answers a request for the
  * other quantity at the SAME point (bit 2: StrongWolfe asks for f, then for f' once Armijo holds, NO.f90:1483-1485) by
  * itself instead of handing it back, so the caller sees one round per distinct trial point -- like the fused kernels --
