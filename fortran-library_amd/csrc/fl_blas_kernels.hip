@@ -542,12 +542,19 @@ int fl_dgemm_strided(int transA, int transB, int M, int K, int N, double alpha, 
     g.A = A_dev; g.B = B_dev; g.C = C_dev;
     g.strideA = strideA; g.strideB = strideB; g.strideC = strideC;
     const int tiles128 = ((M + 127) / 128) * ((N + 127) / 128), tiles64 = ((M + 63) / 64) * ((N + 63) / 64);
-    if ((long long)tiles128 * batch >= 256) // at least one 128-tile per CU
-        hipLaunchKernelGGL((fl::dgemm_kernel<128, 2, 4>), dim3(tiles128, batch), dim3(512), 0,
-                           static_cast<hipStream_t>(stream), g);
-    else
-        hipLaunchKernelGGL((fl::dgemm_kernel<64, 2, 2>), dim3(tiles64, batch), dim3(256), 0, static_cast<hipStream_t>(stream),
-                           g);
+    const bool big = (long long)tiles128 * batch >= 256; // at least one 128-tile per CU
+    // the matrix index is gridDim.y (at most 65535): longer batches go in chunks
+    for (int b0 = 0; b0 < batch; b0 += FL_GRID_YZ_MAX) {
+        const int nb = batch - b0 < FL_GRID_YZ_MAX ? batch - b0 : FL_GRID_YZ_MAX;
+        fl::GemmArgs gc = g;
+        gc.A = g.A + (size_t)b0 * strideA;
+        gc.B = g.B + (size_t)b0 * strideB;
+        gc.C = g.C + (size_t)b0 * strideC;
+        if (big)
+            hipLaunchKernelGGL((fl::dgemm_kernel<128, 2, 4>), dim3(tiles128, nb), dim3(512), 0, static_cast<hipStream_t>(stream), gc);
+        else
+            hipLaunchKernelGGL((fl::dgemm_kernel<64, 2, 2>), dim3(tiles64, nb), dim3(256), 0, static_cast<hipStream_t>(stream), gc);
+    }
     return fl::launch_status();
 }
 

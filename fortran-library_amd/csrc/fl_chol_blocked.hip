@@ -15,7 +15,9 @@
 // -- the products with the W_k again dgemm calls (N = 1), O(n^2) in all.
 // Inverse: X = L^{-1} by the same forward recurrence on the identity (row blocks of X), then A^{-1} = X^T X
 // (dgemm 'T','N'), both triangles written -- which is My_dpotri followed by dsyL2U.
-// LAPACK's info: index of the first non-positive pivot; the matrix is left partially factorised and b untouched.
+// LAPACK's info: index of the first non-positive pivot; fl_dposv_blocked leaves that matrix as the failure found it
+// (block columns before the failing one factorised, the failing diagonal block partially, behind it the Schur
+// complement of the completed block steps) and b untouched; fl_dpotri_blocked leaves A unspecified where info != 0.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -36,9 +38,14 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(int n, int k0, double *A
     __shared__ double Wt[CNB][CNB + 1];
     __shared__ int bad;
     const int mat = blockIdx.x, tid = threadIdx.x;
-    if (info[mat] != 0) return; // an earlier block failed: the reference stops there too
     double *A = A_all + (size_t)mat * strideA + (size_t)k0 * lda + k0;
     double *W = W_all + (size_t)mat * strideW + (size_t)(k0 / CNB) * CNB * CNB;
+    if (info[mat] != 0) { // an earlier block failed: the reference stops there too.  W = 0 makes this block column's
+                          // panel product P = A21 W^T vanish, so the trailing update subtracts nothing; the copy of P
+                          // over A21 is skipped for this matrix (copy_block_kernel): A stays as the failure left it
+        for (int e = tid; e < CNB * CNB; e += 256) W[e] = 0.0;
+        return;
+    }
     const int nb = (n - k0 < CNB) ? n - k0 : CNB;
     for (int e = tid; e < CNB * CNB; e += 256) {
         const int c = e / CNB, r = e - c * CNB;
@@ -73,7 +80,10 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(int n, int k0, double *A
         const int c = e / CNB, r = e - c * CNB;
         if (r < nb && c < nb && r >= c) A[(size_t)c * lda + r] = S[c][r];
     }
-    if (bad) return;
+    if (bad) { // (see above: no panel, no trailing update for this matrix from here on)
+        for (int e = tid; e < CNB * CNB; e += 256) W[e] = 0.0;
+        return;
+    }
     // W = L^{-1} by doubling: the inverse of [A 0; B C] is [A^-1 0; -C^-1 B A^-1  C^-1].  Diagonal 1 x 1 blocks first,
     // then pairs of adjacent s x s blocks for s = 1, 2, 4, ..., 32: T = B A^-1 and X = -C^-1 T are s x s products over
     // the whole workgroup (a thread-per-column substitution would be a 2000-step dependent chain of LDS reads).
@@ -110,13 +120,25 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(int n, int k0, double *A
 }
 
 // dst(rows x cols, ldd) = src(rows x cols, lds) for every matrix of a strided batch
+// (skip: per-matrix flags, e.g. info -- a matrix whose flag is non-zero is left alone; may be NULL)
 __global__ __launch_bounds__(256) void copy_block_kernel(int rows, int cols, const double *src, int lds_, size_t strideS,
-                                                         double *dst, int ldd, size_t strideD)
+                                                         double *dst, int ldd, size_t strideD, const int32_t *skip)
 {
+    if (skip && skip[blockIdx.z] != 0) return;
     const double *s = src + (size_t)blockIdx.z * strideS;
     double *d = dst + (size_t)blockIdx.z * strideD;
     const int r = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
     if (r < rows && c < cols) d[(size_t)c * ldd + r] = s[(size_t)c * lds_ + r];
+}
+// the matrix index is gridDim.z / gridDim.y (at most 65535): longer batches go in chunks
+static void copy_blocks(int batch, hipStream_t st, int rows, int cols, const double *src, int lds_, size_t strideS, double *dst, int ldd,
+                        size_t strideD, const int32_t *skip)
+{
+    for (int b0 = 0; b0 < batch; b0 += FL_GRID_YZ_MAX) {
+        const int nb = batch - b0 < FL_GRID_YZ_MAX ? batch - b0 : FL_GRID_YZ_MAX;
+        hipLaunchKernelGGL(copy_block_kernel, dim3((rows + 255) / 256, cols, nb), dim3(256), 0, st, rows, cols, src + (size_t)b0 * strideS,
+                           lds_, strideS, dst + (size_t)b0 * strideD, ldd, strideD, skip ? skip + b0 : nullptr);
+    }
 }
 // X(n x n, ld) = 0 with a unit diagonal block written where asked (rows k0..k0+nb of the identity)
 __global__ __launch_bounds__(256) void fill_kernel(int rows, int cols, double *X, int ld, size_t stride, int diag_row0)
@@ -161,8 +183,7 @@ static int potrf(const Chol &c)
         // P = A21 W11^T   (rest x nb): B operand given as N x K = W itself (element (k, n) of W^T is W(n, k))
         int rc = gemm(c, 0, 1, rest, nb, nb, 1.0, A21, c.lda, c.strideA, Wk, CNB, c.strideW, 0.0, c.P, n, c.strideP, 0);
         if (rc != FL_OK) return rc;
-        hipLaunchKernelGGL(copy_block_kernel, dim3((rest + 255) / 256, nb, c.batch), dim3(256), 0, c.st, rest, nb, c.P, n,
-                           c.strideP, const_cast<double *>(A21), c.lda, c.strideA);
+        copy_blocks(c.batch, c.st, rest, nb, c.P, n, c.strideP, const_cast<double *>(A21), c.lda, c.strideA, c.info);
         // A22 -= P P^T (lower tiles)
         double *A22 = c.A + (size_t)(k0 + nb) * c.lda + k0 + nb;
         rc = gemm(c, 0, 1, rest, nb, rest, -1.0, c.P, n, c.strideP, c.P, n, c.strideP, 1.0, A22, c.lda, c.strideA, 1);
@@ -185,8 +206,7 @@ static int forward(const Chol &c, double *T, int nrhs, size_t strideT, double *t
         const double *Wk = c.W + (size_t)(k0 / CNB) * CNB * CNB;
         int rc = gemm(c, 0, 0, nb, nb, nrhs, 1.0, Wk, CNB, c.strideW, T + k0, n, strideT, 0.0, tmp, CNB, strideTmp, 0);
         if (rc != FL_OK) return rc;
-        hipLaunchKernelGGL(copy_block_kernel, dim3(1, nrhs, c.batch), dim3(256), 0, c.st, nb, nrhs, tmp, CNB, strideTmp,
-                           T + k0, n, strideT);
+        copy_blocks(c.batch, c.st, nb, nrhs, tmp, CNB, strideTmp, T + k0, n, strideT, nullptr);
     }
     return launch_status();
 }
@@ -204,8 +224,7 @@ static int backward(const Chol &c, double *T, int nrhs, size_t strideT, double *
         const double *Wk = c.W + (size_t)(k0 / CNB) * CNB * CNB;
         int rc = gemm(c, 1, 0, nb, nb, nrhs, 1.0, Wk, CNB, c.strideW, T + k0, n, strideT, 0.0, tmp, CNB, strideTmp, 0);
         if (rc != FL_OK) return rc;
-        hipLaunchKernelGGL(copy_block_kernel, dim3(1, nrhs, c.batch), dim3(256), 0, c.st, nb, nrhs, tmp, CNB, strideTmp,
-                           T + k0, n, strideT);
+        copy_blocks(c.batch, c.st, nb, nrhs, tmp, CNB, strideTmp, T + k0, n, strideT, nullptr);
     }
     return launch_status();
 }
@@ -256,7 +275,11 @@ int fl_dposv_blocked(int batch, int n, double *A_dev, int lda, double *b_dev, in
     if (hipMemcpyAsync(t, b_dev, sizeof(double) * (size_t)batch * n, hipMemcpyDeviceToDevice, st) != hipSuccess) return FL_ERR_LAUNCH;
     if ((rc = fl::forward(c, t, 1, (size_t)n, tmp, (size_t)fl::CNB)) != FL_OK) return rc;
     if ((rc = fl::backward(c, t, 1, (size_t)n, tmp, (size_t)fl::CNB)) != FL_OK) return rc;
-    hipLaunchKernelGGL(fl::commit_rhs_kernel, dim3((n + 255) / 256, batch), dim3(256), 0, st, n, t, b_dev, info_dev);
+    for (int b0 = 0; b0 < batch; b0 += FL_GRID_YZ_MAX) {
+        const int nb = batch - b0 < FL_GRID_YZ_MAX ? batch - b0 : FL_GRID_YZ_MAX;
+        hipLaunchKernelGGL(fl::commit_rhs_kernel, dim3((n + 255) / 256, nb), dim3(256), 0, st, n, t + (size_t)b0 * n, b_dev + (size_t)b0 * n,
+                           info_dev + b0);
+    }
     return fl::launch_status();
 }
 
@@ -274,10 +297,13 @@ int fl_dpotri_blocked(int batch, int n, double *A_dev, int lda, double *X_dev, i
     double *tmp = c.P + (size_t)batch * c.strideP; // [batch][CNB][n]
     if ((rc = fl::potrf(c)) != FL_OK) return rc;
     // X = L^{-1}: forward substitution on the identity
-    hipLaunchKernelGGL(fl::fill_kernel, dim3((n + 255) / 256, n, batch), dim3(256), 0, st, n, n, X_dev, n, (size_t)n * n, 0);
+    for (int b0 = 0; b0 < batch; b0 += FL_GRID_YZ_MAX) {
+        const int nb = batch - b0 < FL_GRID_YZ_MAX ? batch - b0 : FL_GRID_YZ_MAX;
+        hipLaunchKernelGGL(fl::fill_kernel, dim3((n + 255) / 256, n, nb), dim3(256), 0, st, n, n, X_dev + (size_t)b0 * n * n, n, (size_t)n * n, 0);
+    }
     if ((rc = fl::forward(c, X_dev, n, (size_t)n * n, tmp, (size_t)fl::CNB * n)) != FL_OK) return rc;
-    // A^{-1} = X^T X.  (Where the factorisation failed the result is meaningless, like after LAPACK's early return the
-    // matrix holds the partial factor: info says so.)
+    // A^{-1} = X^T X.  (Where the factorisation failed -- info != 0 -- the content of A is unspecified: the reference's
+    // My_dpotri does not call dpotri then and leaves the partial factor, which no caller of it reads either.)
     rc = fl_dgemm_strided(1, 0, n, n, n, 1.0, X_dev, n, (size_t)n * n, X_dev, n, (size_t)n * n, 0.0, A_dev, lda, (size_t)n * lda,
                           batch, 0, st);
     return rc;

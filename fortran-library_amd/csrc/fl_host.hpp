@@ -5,6 +5,8 @@
 #include <cstddef>
 #include "../../include/fl_nlopt.h"
 
+#define FL_GRID_YZ_MAX 65535 // gridDim.y / gridDim.z limit: launchers that put the matrix index there go in chunks
+
 namespace fl {
 
 // status of the launch(es) just issued on this thread: a failed launch (too much LDS for the device, an invalid

@@ -170,8 +170,12 @@ int fl_newton_raphson_batched(int objective, int batch, int n, double *x_dev, co
  *   fl_dposv_batched  <- My_dposv  LinearAlgebra.f90:719-730: A <- Cholesky factor, b [batch][n] <- A^{-1} b
  *   fl_dpotri_batched <- My_dpotri LinearAlgebra.f90:798-812 + dsyL2U 260-265: A <- A^{-1} (both triangles);
  *                        work_dev: one more [batch][n][ld] buffer
- * info_dev[batch]: 0 or the index of the first non-positive pivot (then b / A are left as the reference leaves
- * them: b untouched, A partially factorised). */
+ * info_dev[batch]: 0 or the index of the first non-positive pivot.  Such a matrix does not disturb the others of the
+ * batch; fl_dposv_batched leaves its b untouched and its A partially factorised (as far as the failure: with the blocked
+ * path the block columns before the failing 64-column block, and that block's diagonal part up to the pivot; behind it
+ * the Schur complement of the completed block steps, like a right-looking LAPACK dpotrf); fl_dpotri_batched leaves its A unspecified (the reference's My_dpotri skips dpotri then and
+ * nothing reads the partial factor).  Any batch size (launches go in chunks of 65535 matrices where a grid dimension
+ * carries the matrix index). */
 /* Size: n < 512 runs one workgroup per matrix with sums in sequential order (what the oracle replays bit for bit);
  * from n = 512 on -- any n, also beyond 4096 -- fl_dposv_batched / fl_dpotri_batched run a blocked right-looking
  * Cholesky with many workgroups per matrix whose O(n^3) part is on the f64 matrix cores (csrc/fl_chol_blocked.hip);

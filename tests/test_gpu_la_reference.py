@@ -228,3 +228,69 @@ def test_my_dsyev_values_only_edge_cases(n):
         norm = max(np.abs(A).sum(axis=1).max(), 1e-300)
         assert np.all(np.diff(w) >= 0), name
         assert np.abs(w - ref).max() <= 4 * max(n, 4) * 2.3e-16 * norm + 1e-300, (name, np.abs(w - ref).max(), norm)
+
+
+def test_blocked_cholesky_a_failing_matrix_in_the_middle_of_a_batch_disturbs_nothing():
+    """n = 600 (blocked multi-workgroup path): matrix 2 of 5 is indefinite from its 3rd 64-column block on.  The others
+    are solved as if it were not there; the failing one reports LAPACK's info, keeps its right-hand side, has its first
+    two block columns factorised and, behind the failing block, the Schur complement of those two steps -- no NaN anywhere."""
+    import torch
+    import FortranLibrary.NonlinearOptimization as NLO
+    dev = torch.device("cuda:0")
+    B, n = 5, 600
+    T, E = NLO.reduction_geometry(n)
+    ld = T * E
+    g = torch.Generator(device="cpu").manual_seed(11)
+    G = torch.randn(B, n, n, generator=g, dtype=torch.float64)
+    spd = G @ G.transpose(1, 2) / n + torch.eye(n, dtype=torch.float64)
+    bad_at = 150  # inside the third block (columns 128..191)
+    spd[2, bad_at, bad_at] = -5.0
+    A0 = torch.zeros(B, n, ld, dtype=torch.float64)
+    A0[:, :, :n] = spd  # symmetric: row / column major agree
+    rhs0 = torch.randn(B, n, generator=g, dtype=torch.float64)
+    A, rhs = A0.to(dev), rhs0.to(dev)
+    info = NLO.dposv(A, rhs).cpu().numpy()
+    Ah, xh = A.cpu(), rhs.cpu()
+    assert info[2] == bad_at + 1 and all(info[k] == 0 for k in (0, 1, 3, 4))
+    assert bool(torch.isfinite(Ah).all()) and bool(torch.isfinite(xh).all())
+    for k in (0, 1, 3, 4):
+        assert float((spd[k] @ xh[k] - rhs0[k]).abs().max()) < 1e-9
+    assert torch.equal(xh[2], rhs0[2])  # b untouched (My_dposv, LA.f90:718)
+    # column-major A[k][col][row]: block columns 0..127 hold the factor (L L^T reproduces that part of the matrix) ...
+    L = torch.tril(Ah[2, :128, :n].T)[:, :128]  # rows x first 128 columns
+    assert float((L[:128] @ L[:128].T - spd[2, :128, :128]).abs().max()) < 1e-10
+    assert float((L[128:] @ L[:128].T - spd[2, 128:, :128]).abs().max()) < 1e-10
+    # ... and behind the failing block column the lower triangle holds what a right-looking factorisation has there after
+    # two completed block steps -- the Schur complement A22 - L21 L21^T -- untouched by the failing step and the ones after
+    S = spd[2, 192:, 192:] - L[192:] @ L[192:].T
+    got = Ah[2, 192:n, 192:n].T  # [row, col]
+    assert float((torch.tril(got) - torch.tril(S)).abs().max()) < 1e-10
+    # the inverse: the healthy matrices are inverted, the failing one only reports
+    A2 = A0.to(dev)
+    info2 = NLO.dpotri(A2).cpu().numpy()
+    assert info2[2] == bad_at + 1 and all(info2[k] == 0 for k in (0, 1, 3, 4))
+    for k in (0, 1, 3, 4):
+        assert float((A2[k, :, :n].cpu() @ spd[k] - torch.eye(n, dtype=torch.float64)).abs().max()) < 1e-8
+
+
+def test_batches_beyond_65535_matrices_go_in_chunks():
+    """the strided DGEMM (matrix index in gridDim.y) under the batched TrustRegion: 70 000 tiny systems at once"""
+    import torch
+    import FortranLibrary.NonlinearOptimization as NLO
+    dev = torch.device("cuda:0")
+    B, n, m = 70000, 3, 4
+    t = torch.linspace(0.5, 2.0, B, dtype=torch.float64, device=dev)
+
+    def fun(x, rq):  # r = (x0 - t, x1 - 2 t, x2 + t, x0 x1 - 2 t^2): root (t, 2t, -t)
+        r = torch.stack([x[:, 0] - t, x[:, 1] - 2 * t, x[:, 2] + t, x[:, 0] * x[:, 1] - 2 * t * t], dim=1)
+        J = torch.zeros(x.shape[0], n, m, dtype=torch.float64, device=dev)
+        J[:, 0, 0] = 1.0
+        J[:, 1, 1] = 1.0
+        J[:, 2, 2] = 1.0
+        J[:, 0, 3] = x[:, 1]
+        J[:, 1, 3] = x[:, 0]
+        return r, J
+    x = torch.ones(B, n, dtype=torch.float64, device=dev)
+    out = NLO.TrustRegion(x, fun, m, Precision=1e-10)
+    sol = torch.stack([t, 2 * t, -t], dim=1)
+    assert float((x - sol).abs().max()) < 1e-8 and bool((out["reason"] == 3).all())
