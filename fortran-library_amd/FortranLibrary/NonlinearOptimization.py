@@ -303,7 +303,30 @@ def _f64c(t):
     return t if (t.dtype == torch.float64 and t.is_contiguous()) else t.to(torch.float64).contiguous()
 
 
-def minimize_rci(solver, x, fun, options=None, max_steps=10000000, check_every=8, mode="legacy", compact_below=0.5, **kw):
+REQ_H = 16
+if hasattr(FL, "fl_rci_put_hessians"):
+    FL.fl_rci_put_hessians.argtypes = [_vp, _dp, _ip]
+    FL.fl_rci_auglag_miu.argtypes = [_vp, _dp]
+    FL.fl_fd_points.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, _dp, _dp, _dp, _vp]
+    FL.fl_fd_column.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, _dp, _dp, _dp, _dp, _vp]
+
+
+def numerical_hessian(grad, x, eps=1e-8):
+    """f'' of a batch by central differences of `grad(x) -> g[batch, n]` with MKL djacobi's step rule (fl_fd_points /
+    fl_fd_column): what the reference does when no fdd is passed (NO.f90:676, 981, 1067).  2n gradient evaluations of
+    the batch; returns H [batch, n, n] (H[k, j, :] = column j)."""
+    import torch
+    B, n = x.shape
+    H = torch.empty(B, n, n, dtype=torch.float64, device=x.device)
+    xp, xm = torch.empty_like(x), torch.empty_like(x)
+    for j in range(n):
+        _check(FL.fl_fd_points(B, n, j, eps, _ptr(x), _ptr(xp), _ptr(xm), _stream()), "fl_fd_points")
+        gp, gm = _f64c(grad(xp)), _f64c(grad(xm))
+        _check(FL.fl_fd_column(B, n, j, eps, _ptr(x), _ptr(gp), _ptr(gm), _ptr(H), _stream()), "fl_fd_column")
+    return H
+
+
+def minimize_rci(solver, x, fun, options=None, max_steps=10000000, check_every=8, mode="legacy", compact_below=0.5, hess=None, **kw):
     """Batched minimisation of a user objective by reverse communication (fl_rci_*); x [batch, n] is updated in place.
     The solver machines run in the HIP kernels; only the objective is the caller's.  solver: SD | CG | LBFGS_ | BFGS_.
 
@@ -317,10 +340,16 @@ def minimize_rci(solver, x, fun, options=None, max_steps=10000000, check_every=8
         gathered once per change, not per call); returns (f[n_active], g[n_active, n]).  The list is re-compacted when
         fewer than `compact_below` of its problems are still running: the tail of the slowest problems costs
         evaluations of those problems only.
+    Hessians (solver 4 = NewtonRaphson, or BFGS_ with ExactStep > 0; mode "legacy"): `hess(x) -> f''[batch, n, n]` is
+    called where a problem asks for it (the reference's fdd); hess="numerical": central differences of fun's gradient with
+    djacobi's step rule, like the reference without fdd.
     The request vector is brought to the host only every `check_every` steps."""
     import torch
     o = options if options is not None else default_options(solver, **kw)
     B, n, out = _prep(x, None, None)
+    wants_h = solver == 4 or (solver == BFGS_ and o.exact_step > 0)
+    if wants_h and (hess is None or mode != "legacy"):
+        raise ValueError("NewtonRaphson / BFGS with ExactStep > 0 by reverse communication: pass hess=callable | 'numerical' (mode 'legacy')")
     h = C.c_void_p()
     _check(FL.fl_rci_create(C.byref(h), solver, B, n, C.byref(o), _stream()), "fl_rci_create")
     try:
@@ -357,6 +386,9 @@ def minimize_rci(solver, x, fun, options=None, max_steps=10000000, check_every=8
             while steps < max_steps:
                 if steps % check_every == 0 and not bool((req != 0).any()):
                     break
+                if wants_h and bool((req & REQ_H).any()):  # f''(x) for the problems that ask (their x is unchanged)
+                    Hn = numerical_hessian(lambda xx: fun(xx)[1], x) if hess == "numerical" else _f64c(hess(x))
+                    _check(FL.fl_rci_put_hessians(h, _ptr(Hn), _ptr(req)), "fl_rci_put_hessians")
                 fn, gn = fun(x, req) if mode == "full" else fun(x)
                 _check(step(_ptr(_f64c(fn)), _ptr(_f64c(gn))), "fl_rci_step")
                 steps += 1
@@ -369,14 +401,38 @@ def minimize_rci(solver, x, fun, options=None, max_steps=10000000, check_every=8
     return out
 
 
-def minimize_rci_auglag(solver, x, fun, M, lambda0=None, miu0=1.0, options=None, max_steps=10000000, check_every=8, **kw):
+def auglag_hessian(fdd, cdd, cd, c, lam, miu):
+    """The Hessian of the augmented Lagrangian exactly as the reference's Ldd forms it (NO.f90:2229-2241):
+        Ldd = (f'' + sum_j c_j'' (miu c_j - lambda_j)) + cd cd^T        -- no miu on the last term, as written.
+    fdd [B, n, n], cdd [B, M, n, n] (or None: linear constraints), cd [B, M, n], c, lam [B, M], miu [B].  Element-wise
+    operations in the reference's order, so a caller whose fdd / cdd have the oracle's bits gets the oracle's Hessian."""
+    v = miu[:, None] * c - lam
+    H = fdd
+    if cdd is not None:
+        t = 0.0 + cdd[:, 0] * v[:, 0, None, None]
+        for j in range(1, cdd.shape[1]):
+            t = t + cdd[:, j] * v[:, j, None, None]
+        H = H + t
+    pp = 0.0 + cd[:, 0, :, None] * cd[:, 0, None, :]
+    for j in range(1, cd.shape[1]):
+        pp = pp + cd[:, j, :, None] * cd[:, j, None, :]
+    return H + pp
+
+
+def minimize_rci_auglag(solver, x, fun, M, lambda0=None, miu0=1.0, options=None, max_steps=10000000, check_every=8, hess=None, **kw):
     """AugmentedLagrangian (NO.f90:2005) for a batch with the caller's objective AND equality constraints, by reverse
     communication: `fun(x)` returns (f[batch], g[batch, n], c[batch, M], cd[batch, M, n]) CUDA tensors for the whole
-    batch (cd[k, j] = grad c_j at x_k).  solver: LBFGS_ | CG | BFGS_ with ExactStep <= 0 (the inner solver).  x is updated in place; returns the
-    usual outputs plus "lambda" [batch, M], "cnorm2", "outer"."""
+    batch (cd[k, j] = grad c_j at x_k).  solver (the inner one): LBFGS_ | CG | BFGS_ | 4 (NewtonRaphson).  NewtonRaphson, and
+    BFGS_ with ExactStep > 0, take the Hessian of L (the reference's fdd / cdd branch, NO.f90:2074-2148): pass
+    hess=callable `hess(x) -> (fdd[batch, n, n], cdd[batch, M, n, n] | None)` -- Ldd is assembled from them as the reference
+    does (auglag_hessian) -- or hess="numerical": central differences of grad L with djacobi's step rule, like the reference
+    when fdd / cdd are absent.  x is updated in place; returns the usual outputs plus "lambda" [batch, M], "cnorm2", "outer"."""
     import torch
     o = options if options is not None else default_options(solver, **kw)
     B, n, out = _prep(x, None, None)
+    wants_h = solver == 4 or (solver == BFGS_ and o.exact_step > 0)
+    if wants_h and hess is None:
+        raise ValueError("NewtonRaphson / BFGS with ExactStep > 0 inside: pass hess=callable | 'numerical'")
     lam = torch.zeros(B, M, dtype=torch.float64, device=x.device) if lambda0 is None else \
         lambda0.to(torch.float64).contiguous().clone()
     FL.fl_rci_create_auglag.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double,
@@ -394,6 +450,22 @@ def minimize_rci_auglag(solver, x, fun, M, lambda0=None, miu0=1.0, options=None,
             if steps % check_every == 0 and not bool((req != 0).any()):
                 break
             fn, gn, cn, cdn = (t.to(torch.float64).contiguous() for t in fun(x))
+            if wants_h and bool((req & REQ_H).any()):  # the Hessian of L at the (unchanged) current points
+                miu = torch.empty(B, dtype=torch.float64, device=x.device)
+                _check(FL.fl_rci_auglag_miu(h, _ptr(miu)), "fl_rci_auglag_miu")
+                if hess == "numerical":
+                    def grad_l(xx):  # grad L = f' + cd^T (miu c - lambda), the sum over the constraints in order (NO.f90:2205)
+                        _, g2, c2, cd2 = fun(xx)
+                        v = miu[:, None] * c2 - lam
+                        t = 0.0 + cd2[:, 0] * v[:, 0, None]
+                        for j in range(1, M):
+                            t = t + cd2[:, j] * v[:, j, None]
+                        return g2 + t
+                    Hn = numerical_hessian(grad_l, x)
+                else:
+                    fdd, cdd = hess(x)
+                    Hn = _f64c(auglag_hessian(fdd, cdd, cdn, cn, lam, miu))
+                _check(FL.fl_rci_put_hessians(h, _ptr(Hn), _ptr(req)), "fl_rci_put_hessians")
             _check(FL.fl_rci_step_auglag(h, _ptr(x), _ptr(fn), _ptr(gn), _ptr(cn), _ptr(cdn), _ptr(req)),
                    "fl_rci_step_auglag")
             steps += 1

@@ -210,6 +210,57 @@ __global__ __launch_bounds__(NW * 64) void line_search_step_kernel(int n, int ns
     }
 }
 
+// H_src [batch][n][n] dense column-major -> the handle's padded buffer (problem k at dst + k * stride, ld) for the problems
+// whose request carries FL_REQ_H (all of them when request == nullptr)
+__global__ __launch_bounds__(256) void put_hessians_kernel(int n, const double *H_src, double *dst, size_t stride, int ld,
+                                                           const int32_t *request)
+{
+    const int k = blockIdx.y, col = blockIdx.x;
+    if (request && !(request[k] & FL_REQ_H)) return;
+    const double *s = H_src + ((size_t)k * n + col) * n;
+    double *d = dst + (size_t)k * stride + (size_t)col * ld;
+    for (int r = threadIdx.x; r < n; r += 256) d[r] = s[r];
+}
+// the augmented Lagrangian's penalty parameter per problem, from the parked machines
+__global__ void get_miu_kernel(int batch, const double *sc_all, int scalars, double miu_first, int first, double *miu)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < batch) miu[k] = first ? miu_first : sc_all[(size_t)k * scalars + 40];
+}
+// Central differences with MKL djacobi's step rule (fl_host.hpp: central_difference_jacobian), for a batch:
+//   fd_points:  xp = x with coordinate j at x_j (1 + eps) | x_j + eps,  xm likewise with (1 - eps) | - eps
+//   fd_column:  H(:, j) of every problem = (gp - gm) * (0.5 / h_j),  h_j = eps x_j | eps  (H [batch][n][n] column-major)
+__global__ __launch_bounds__(256) void fd_points_kernel(int batch, int n, int j, double eps, const double *x, double *xp, double *xm)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)batch * n) return;
+    const int i = (int)(e % n);
+    const double v = x[e];
+    double a = v, b = v;
+    if (i == j) {
+        if (fabs(v) > eps) {
+            a = v * (1.0 + eps);
+            b = v * (1.0 - eps);
+        } else {
+            a = v + eps;
+            b = v - eps;
+        }
+    }
+    xp[e] = a;
+    xm[e] = b;
+}
+__global__ __launch_bounds__(256) void fd_column_kernel(int batch, int n, int j, double eps, const double *x, const double *gp,
+                                                        const double *gm, double *H)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)batch * n) return;
+    const size_t k = e / n;
+    const int i = (int)(e % n);
+    const double xj = x[k * n + j];
+    const double h = fabs(xj) > eps ? eps * xj : eps;
+    H[(k * n + j) * n + i] = (gp[e] - gm[e]) * (0.5 / h);
+}
+
 struct Rci {
     int solver, batch, n, nw, ept, first;
     int aug; // augmented Lagrangian around the inner solver: c, cd come with the evaluations
@@ -236,7 +287,11 @@ static void launch_rci(Rci *h, const double *f, const double *g, const double *c
                   // BFGS (2131-2148 with ExactStep <= 0: every outer round rebuilds H from a I)
         if (h->solver == FL_SOLVER_CG) FL_RCI_AUG(FL_SOLVER_CG);
         else if (h->solver == FL_SOLVER_BFGS) FL_RCI_AUG(FL_SOLVER_BFGS);
-        else FL_RCI_AUG(FL_SOLVER_LBFGS);
+        else if (h->solver == FL_SOLVER_NEWTON) {
+            // NewtonRaphson around the caller's Hessian of L (NO.f90:2074-2130): up to n = 2048 like the fused kernels (at
+            // 512 threads the Cholesky kernels and the constraint terms together do not fit 256 VGPRs)
+            if constexpr (NW < 8) FL_RCI_AUG(FL_SOLVER_NEWTON);
+        } else FL_RCI_AUG(FL_SOLVER_LBFGS);
         return;
     }
     switch (h->solver) {
@@ -427,12 +482,13 @@ int fl_rci_step(fl_rci *h, double *x_dev, const double *f_dev, const double *g_d
 int fl_rci_create_auglag(fl_rci **out, int solver, int batch, int n, int m, double *lambda_dev, double miu0,
                          const fl_options *opt, void *stream)
 {
-    if (solver != FL_SOLVER_LBFGS && solver != FL_SOLVER_CG && solver != FL_SOLVER_BFGS) return FL_ERR_INVALID_ARGUMENT;
-    // BFGS: quasi-Newton updates only -- the exact inverse Hessian of L (NO.f90:2229-2241) needs f'' and every c_j'',
-    // which this protocol does not carry (the fused kernel and the one-problem legacy symbol have that branch)
-    if (solver == FL_SOLVER_BFGS && (!opt || opt->exact_step > 0)) return FL_ERR_INVALID_ARGUMENT;
-    if (m < 1 || m > FL_MAX_CONSTRAINTS || !lambda_dev) return FL_ERR_INVALID_ARGUMENT;
+    if (solver != FL_SOLVER_LBFGS && solver != FL_SOLVER_CG && solver != FL_SOLVER_BFGS && solver != FL_SOLVER_NEWTON)
+        return FL_ERR_INVALID_ARGUMENT;
+    if (!opt || m < 1 || m > FL_MAX_CONSTRAINTS || !lambda_dev) return FL_ERR_INVALID_ARGUMENT;
     if (n > 4096) return FL_ERR_UNSUPPORTED_SIZE; // like fl_augmented_lagrangian_batched: the register path only
+    // NewtonRaphson, and BFGS with exact_step > 0, ask for the Hessian of L (FL_REQ_H: NO.f90:2229-2241, Ldd): up to
+    // n = 2048, like the fused kernels' own exact inner solvers
+    if ((solver == FL_SOLVER_NEWTON || (solver == FL_SOLVER_BFGS && opt->exact_step > 0)) && n > 2048) return FL_ERR_UNSUPPORTED_SIZE;
     const int rc = fl_rci_create(out, solver, batch, n, opt, stream);
     if (rc != FL_OK) return rc;
     fl::Rci &r = (*out)->r;
@@ -480,6 +536,58 @@ int fl_rci_hessian_buffer(fl_rci *h, double **hessian_dev, int *ld)
     else return FL_ERR_INVALID_ARGUMENT;
     *ld = (int)npad;
     return FL_OK;
+}
+
+// H_dev [batch][n][n] (dense, column-major -- a Hessian is symmetric, so row-major is the same) -> the handle's buffer, for
+// the problems whose request asks for it (request_dev == NULL: all)
+int fl_rci_put_hessians(fl_rci *h, const double *H_dev, const int32_t *request_dev)
+{
+    double *dst = nullptr;
+    int ld = 0;
+    if (!h || !H_dev) return FL_ERR_INVALID_ARGUMENT;
+    const int rc = fl_rci_hessian_buffer(h, &dst, &ld);
+    if (rc != FL_OK) return rc;
+    const size_t mat = (size_t)h->r.n * ld, stride = (h->r.solver == FL_SOLVER_NEWTON) ? mat : 3 * mat;
+    for (int b0 = 0; b0 < h->r.batch; b0 += FL_GRID_YZ_MAX) {
+        const int nb = h->r.batch - b0 < FL_GRID_YZ_MAX ? h->r.batch - b0 : FL_GRID_YZ_MAX;
+        hipLaunchKernelGGL(fl::put_hessians_kernel, dim3(h->r.n, nb), dim3(256), 0, h->r.stream, h->r.n,
+                           H_dev + (size_t)b0 * h->r.n * h->r.n, dst + (size_t)b0 * stride, stride, ld,
+                           request_dev ? request_dev + b0 : nullptr);
+    }
+    return fl::launch_status();
+}
+
+// miu_dev [batch] <- the penalty parameter of every problem's current outer round (an augmented-Lagrangian handle): with
+// lambda_dev (kept up to date by the steps) what a caller needs to form the Hessian of L as the reference's Ldd does,
+//   Ldd = f'' + sum_j c_j'' (miu c_j - lambda_j) + cd cd^T                                   (NO.f90:2229-2241)
+int fl_rci_auglag_miu(fl_rci *h, double *miu_dev)
+{
+    if (!h || !h->r.aug || !miu_dev) return FL_ERR_INVALID_ARGUMENT;
+    const double m0 = h->r.A.miu0 > 1.0 ? h->r.A.miu0 : 1.0;
+    hipLaunchKernelGGL(fl::get_miu_kernel, dim3((h->r.batch + 255) / 256), dim3(256), 0, h->r.stream, h->r.batch, h->r.sc, 48, m0,
+                       h->r.first, miu_dev);
+    return fl::launch_status();
+}
+
+// Central differences of a gradient for a batch, with MKL djacobi's step rule (what the reference does for f'' when no
+// fdd is passed, NO.f90:676, 981, 1067): for j = 0 .. n-1:  fl_fd_points(j) -> evaluate the gradients gp at xp and gm
+// at xm -> fl_fd_column(j) writes column j of every problem's H [batch][n][n].  2n gradient evaluations of the batch.
+int fl_fd_points(int batch, int n, int j, double eps, const double *x_dev, double *xp_dev, double *xm_dev, void *stream)
+{
+    if (batch <= 0 || n <= 0 || j < 0 || j >= n || !(eps > 0.0) || !x_dev || !xp_dev || !xm_dev) return FL_ERR_INVALID_ARGUMENT;
+    const size_t tot = (size_t)batch * n;
+    hipLaunchKernelGGL(fl::fd_points_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), batch, n,
+                       j, eps, x_dev, xp_dev, xm_dev);
+    return fl::launch_status();
+}
+int fl_fd_column(int batch, int n, int j, double eps, const double *x_dev, const double *gp_dev, const double *gm_dev, double *H_dev,
+                 void *stream)
+{
+    if (batch <= 0 || n <= 0 || j < 0 || j >= n || !(eps > 0.0) || !x_dev || !gp_dev || !gm_dev || !H_dev) return FL_ERR_INVALID_ARGUMENT;
+    const size_t tot = (size_t)batch * n;
+    hipLaunchKernelGGL(fl::fd_column_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), batch, n,
+                       j, eps, x_dev, gp_dev, gm_dev, H_dev);
+    return fl::launch_status();
 }
 
 int fl_rci_results(fl_rci *h, double *f_dev, double *gg_dev, int32_t *iters_dev, int32_t *status_dev, int32_t *nf_dev,

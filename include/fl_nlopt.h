@@ -317,7 +317,13 @@ int fl_rci_destroy(fl_rci *handle);
  * opt->max_iteration bounds both loops, opt->increment is the line-search growth factor AND the miu growth factor
  * (as in the reference).  fl_rci_results: f = the augmented Lagrangian at exit, iters = inner iterations of all outer
  * rounds, status = FL_STATUS_CONVERGED (||c|| < Precision) | FL_STATUS_MAXIT; fl_rci_results_auglag: c.c at exit and
- * the number of outer iterations. */
+ * the number of outer iterations.
+ * NewtonRaphson (FL_SOLVER_NEWTON, NO.f90:2074-2130) and BFGS with opt->exact_step > 0 (2131-2148) as inner solvers ask
+ * for the HESSIAN OF L (bit 4, FL_REQ_H = 16, at an unchanged point): the caller forms it as the reference's Ldd does
+ * (NO.f90:2229-2241),  Ldd = f'' + sum_j c_j'' (miu c_j - lambda_j) + cd cd^T  -- lambda from lambda_dev, miu from
+ * fl_rci_auglag_miu -- writes it with fl_rci_put_hessians (or into fl_rci_hessian_buffer) and steps again with the same f,
+ * g, c, cd arrays; n <= 2048 for these two.  Without f'' / c'' the reference differentiates grad L by MKL's djacobi:
+ * fl_fd_points / fl_fd_column do that for a batch with djacobi's step rule (2n gradient evaluations per Hessian). */
 #define FL_RCI_REQ_C 32
 #define FL_RCI_REQ_CD 64
 int fl_rci_create_auglag(fl_rci **handle, int solver, int batch, int n, int m, double *lambda_dev, double miu0,
@@ -325,6 +331,16 @@ int fl_rci_create_auglag(fl_rci **handle, int solver, int batch, int n, int m, d
 int fl_rci_step_auglag(fl_rci *handle, double *x_dev, const double *f_dev, const double *g_dev, const double *c_dev,
                        const double *cd_dev, int32_t *request_dev);
 int fl_rci_results_auglag(fl_rci *handle, double *cnorm2_dev, int32_t *outer_dev);
+int fl_rci_auglag_miu(fl_rci *handle, double *miu_dev); /* [batch]: the penalty parameter of each problem's current outer round */
+/* Hessians for the problems whose request carries bit 4 (request_dev == NULL: all): H_dev [batch][n][n] dense (symmetric, so
+ * row- and column-major agree) -> the handle's padded buffer.  Works for fl_rci_create (f'') and fl_rci_create_auglag (Ldd). */
+int fl_rci_put_hessians(fl_rci *handle, const double *H_dev, const int32_t *request_dev);
+/* Central differences of a gradient for a batch with MKL djacobi's step rule (see fl_djacobi): for j = 0 .. n-1:
+ * fl_fd_points(j): xp_dev / xm_dev [batch][n] <- x with coordinate j at x_j (1 +- eps), or x_j +- eps where |x_j| <= eps;
+ * evaluate the gradients gp at xp, gm at xm; fl_fd_column(j): column j of every H_dev [batch][n][n] <- (gp - gm) * (0.5 / h_j). */
+int fl_fd_points(int batch, int n, int j, double eps, const double *x_dev, double *xp_dev, double *xm_dev, void *stream);
+int fl_fd_column(int batch, int n, int j, double eps, const double *x_dev, const double *gp_dev, const double *gm_dev,
+                 double *H_dev, void *stream);
 
 /* ---- central-difference Jacobian: the library's replacement of MKL's djacobi, which the reference calls for f'' when
  * the caller passes no fdd (NO.f90:676, 981, 1067, 1258: djacobi(fd_j,dim,dim,H,x,1d-8)) and for TrustRegion's Jacobian

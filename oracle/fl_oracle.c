@@ -1158,7 +1158,9 @@ void flo_newton(flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, flo_fdd_t fdd, double *x
     initial_eval(f, fd, f_fd, &fnew, g, x, n, ctx, st);
     st->f = fnew;
     st->gg = flo_dot(n, g, g);
-    fdd(H, x, n, ctx);
+    /* info=fdd(Hessian,x,dim), or -- fdd absent -- djacobi(fd_j,dim,dim,Hessian,x,1d-8) (NO.f90:1065-1067) */
+    if (fdd) fdd(H, x, n, ctx);
+    else central_hessian(fd, H, x, n, ctx, st);
     for (int i = 0; i < n; ++i) p[i] = -g[i];
     info = flo_dposv_lower(H, p, n);
     if (info == 0) {
@@ -1186,7 +1188,8 @@ void flo_newton(flo_f_t f, flo_fd_t fd, flo_ffd_t f_fd, flo_fdd_t fdd, double *x
             break;
         }
         for (int i = 0; i < n; ++i) p[i] = -g[i];
-        fdd(H, x, n, ctx);
+        if (fdd) fdd(H, x, n, ctx);
+        else central_hessian(fd, H, x, n, ctx, st);
         info = flo_dposv_lower(H, p, n);
         if (info == 0) {
             phidnew = flo_dot(n, g, p);

@@ -216,8 +216,9 @@ int flo_auglag_batch(int solver, int kind, int B, int n, int m, double *x, const
         P.b = b ? b + (size_t)k * n : NULL;
         int as = solver == FLO_LBFGS ? 1 : (solver == FLO_CG ? 2 : (solver == 4 ? 3 : 0));
         /* NewtonRaphson, and BFGS with ExactStep > 0, take the analytic Hessians (the fdd / cdd branch) */
-        const int hess = (as == 3) || (as == 0 && o->exact_step > 0);
-        flo_augmented_lagrangian_h(flo_prob_f, flo_prob_fd, use_ffd ? flo_prob_ffd : NULL, hess ? flo_prob_fdd : NULL,
+        /* (use_ffd & 2: the caller passes no fdd / cdd -- the reference then differentiates grad L by MKL's djacobi) */
+        const int hess = ((as == 3) || (as == 0 && o->exact_step > 0)) && !(use_ffd & 2);
+        flo_augmented_lagrangian_h(flo_prob_f, flo_prob_fd, (use_ffd & 1) ? flo_prob_ffd : NULL, hess ? flo_prob_fdd : NULL,
                                    flo_prob_c, flo_prob_cd, hess ? flo_prob_cdd : NULL, x + (size_t)k * n, n, m, as,
                                    lambda + (size_t)k * m, miu0, o, &P, &st, &out, &cc);
         /* objective (not Lagrangian) at the solution */

@@ -9,6 +9,7 @@ Two bars:
     relative (absolute floor 1e-20 when |f*| < 1e-10), minimiser within 1e-8 * max(1, |x*|),
     on inputs where the reference converges by its gradient test.
 """
+import ctypes as C
 import numpy as np
 import pytest
 
@@ -665,6 +666,137 @@ def test_augmented_lagrangian_with_the_hessian_of_L_bitexact(solver_name, solver
     assert np.array_equal(g["x"].view(np.uint64), o["x"].view(np.uint64))
     assert np.array_equal(g["lambda"].view(np.uint64), o["lam"].view(np.uint64))
     assert np.array_equal(g["cnorm2"].view(np.uint64), o["cnorm2"].view(np.uint64))
+
+
+@pytest.mark.parametrize("solver_name,kind,n,m,B,kw", [
+    ("NewtonRaphson", O.QUARTIC, 10, 1, 64, {"Precision": 1e-8}),          # the reference's own test problem as a batch
+    ("NewtonRaphson", O.DIAGQUAD, 64, 8, 64, {"Precision": 1e-8}),
+    ("NewtonRaphson", O.ROSENBROCK, 96, 3, 16, {"Precision": 1e-7, "MaxIteration": 30}),
+    ("BFGS", O.DIAGQUAD, 64, 8, 64, {"Precision": 1e-8, "ExactStep": 5}),
+    ("BFGS", O.ROSENBROCK, 96, 3, 16, {"Precision": 1e-7, "ExactStep": 3, "MaxIteration": 20}),
+    ("NewtonRaphson", O.DIAGQUAD, 24, 3, 8, {"Precision": 1e-7, "numerical": True}),  # no fdd / cdd: djacobi's central differences of grad L
+])
+def test_augmented_lagrangian_with_hessians_by_reverse_communication(solver_name, kind, n, m, B, kw):
+    """AugmentedLagrangian around NewtonRaphson / BFGS(ExactStep > 0) with the CALLER's f, f', c, c', f'', c'' for a batch
+    (fl_rci_*_auglag + FL_REQ_H): the Hessian of L is assembled on the caller's side as the reference's Ldd does
+    (NO.f90:2229-2241) and delivered with fl_rci_put_hessians; without f'' / c'' grad L is differentiated with djacobi's
+    step rule (fl_fd_points / fl_fd_column).  Bit for bit the oracle (flo_augmented_lagrangian_h), B >= 64 where cheap."""
+    NLO = _nlo()
+    kw = dict(kw)
+    numerical = kw.pop("numerical", False)
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(17 * n + m)
+    i = np.arange(1, n + 1).astype(float)
+    x0 = 0.1 + 0.05 * np.cos(i)[None, :] + 0.01 * rng.standard_normal((B, n))
+    if kind == O.QUARTIC:
+        x0 = rng.random((B, n))
+    d = b = None
+    if kind == O.DIAGQUAD:
+        d, b = _quads(B, n, 2.0, 10.0, 5)
+    T, E = NLO.reduction_geometry(n)
+    lib = O.lib()
+    dp = C.POINTER(C.c_double)
+    lib.flo_prob_eval_batch.argtypes = [C.c_int] * 4 + [dp, dp, dp] + [C.c_int] * 4 + [dp] * 4
+    P = lambda a: a.ctypes.data_as(dp) if a is not None else None
+    f_h, g_h, c_h, cd_h = np.zeros(B), np.zeros((B, n)), np.zeros((B, m)), np.zeros((B, m, n))
+
+    def fun(xdev):
+        xh = np.ascontiguousarray(xdev.cpu().numpy())
+        lib.flo_prob_eval_batch(kind, B, n, m, P(xh), P(d), P(b), O.TREE, T, E, 0, P(f_h), P(g_h), P(c_h), P(cd_h))
+        return (torch.tensor(f_h, device=dev), torch.tensor(g_h, device=dev), torch.tensor(c_h, device=dev),
+                torch.tensor(cd_h, device=dev))
+
+    class Prob(C.Structure):
+        _fields_ = [("kind", C.c_int), ("d", dp), ("b", dp)]
+    lib.flo_prob_fdd.argtypes = [dp, dp, C.c_int, C.c_void_p]
+    w = n // m
+    cdd = np.zeros((B, m, n, n))
+    for j in range(m):  # block spheres: c_j'' = 2 I on block j
+        idx = np.arange(j * w, (j + 1) * w)
+        cdd[:, j, idx, idx] = 2.0
+    cdd_t = torch.tensor(cdd, device=dev)
+
+    def hess(xdev):
+        xh = np.ascontiguousarray(xdev.cpu().numpy())
+        H = np.zeros((B, n, n))
+        for k in range(B):
+            pr = Prob(kind, P(d[k]) if d is not None else None, P(b[k]) if b is not None else None)
+            Hk = np.zeros((n, n))
+            lib.flo_prob_fdd(P(Hk), P(xh[k]), n, C.byref(pr))
+            H[k] = Hk
+        return torch.tensor(H, device=dev), cdd_t
+    solver = 4 if solver_name == "NewtonRaphson" else NLO.BFGS_
+    x = torch.tensor(x0, device=dev)
+    out = NLO.minimize_rci_auglag(solver, x, fun, m, check_every=1, hess="numerical" if numerical else hess, **kw)
+    oo = _oracle_opts(O.BFGS if solver_name == "BFGS" else O.LBFGS, kw)
+    oo.exact_step = int(kw.get("ExactStep", 0))
+    O.lib().flo_set_auglag_bfgs_form(1)
+    try:
+        o = O.auglag_batch(4 if solver == 4 else O.BFGS, kind, x0, m, d=d, b=b, opts=oo, sum_mode=O.TREE, threads=T, ept=E,
+                           use_ffd=2 if numerical else 0)
+    finally:
+        O.lib().flo_set_auglag_bfgs_form(0)
+    g = {k: v.cpu().numpy() for k, v in out.items() if hasattr(v, "cpu")}
+    assert np.array_equal(g["outer"], o["outer"]), (g["outer"], o["outer"])
+    assert np.array_equal(g["iters"], o["iters"]), (g["iters"], o["iters"])
+    assert np.array_equal(g["nf"], o["nf"])
+    if not numerical:  # (the oracle counts djacobi's 2n gradient calls per Hessian as the reference's callbacks would be)
+        assert np.array_equal(g["ng"], o["ng"])
+    assert np.array_equal(x.cpu().numpy().view(np.uint64), o["x"].view(np.uint64))
+    assert np.array_equal(g["lambda"].view(np.uint64), o["lam"].view(np.uint64))
+    assert np.array_equal(g["cnorm2"].view(np.uint64), o["cnorm2"].view(np.uint64))
+    if "MaxIteration" not in kw:
+        assert np.all(g["cnorm2"] < oo.precision ** 2)
+    if not numerical:  # ... and the fused kernel with its compiled-in objective, constraints and Hessians: the same bits
+        fused = _gpu_auglag(solver_name, kind, x0, m, d, b, **kw)
+        assert np.array_equal(fused["x"].view(np.uint64), o["x"].view(np.uint64))
+
+
+def test_batched_newton_by_reverse_communication_with_analytic_and_numerical_hessians():
+    """fl_rci_* with FL_SOLVER_NEWTON for a batch: f'' from the caller (fl_rci_put_hessians) -- bit for bit the oracle and the
+    fused kernel -- and by central differences with djacobi's step rule (the reference without fdd, NO.f90:1067)"""
+    NLO = _nlo()
+    dev = torch.device("cuda:0")
+    B, n = 48, 40
+    rng = np.random.default_rng(4)
+    x0 = 1.0 + 0.1 * rng.uniform(-1, 1, (B, n))
+    T, E = NLO.reduction_geometry(n)
+    lib = O.lib()
+    dp = C.POINTER(C.c_double)
+    P = lambda a: a.ctypes.data_as(dp)
+    lib.flo_prob_eval_batch.argtypes = [C.c_int] * 4 + [dp, dp, dp] + [C.c_int] * 4 + [dp] * 4
+    f_h, g_h = np.zeros(B), np.zeros((B, n))
+
+    def fun(xdev):
+        xh = np.ascontiguousarray(xdev.cpu().numpy())
+        lib.flo_prob_eval_batch(O.ROSENBROCK, B, n, 0, P(xh), None, None, O.TREE, T, E, 0, P(f_h), P(g_h), None, None)
+        return torch.tensor(f_h, device=dev), torch.tensor(g_h, device=dev)
+
+    class Prob(C.Structure):
+        _fields_ = [("kind", C.c_int), ("d", dp), ("b", dp)]
+    lib.flo_prob_fdd.argtypes = [dp, dp, C.c_int, C.c_void_p]
+
+    def hess(xdev):
+        xh = np.ascontiguousarray(xdev.cpu().numpy())
+        H = np.zeros((B, n, n))
+        pr = Prob(O.ROSENBROCK, None, None)
+        for k in range(B):
+            Hk = np.zeros((n, n))
+            lib.flo_prob_fdd(P(Hk), P(xh[k]), n, C.byref(pr))
+            H[k] = Hk
+        return torch.tensor(H, device=dev)
+    kw = dict(Precision=1e-10, MaxIteration=60)
+    x = torch.tensor(x0, device=dev)
+    out = NLO.minimize_rci(4, x, fun, check_every=1, hess=hess, **kw)
+    o = O.solve_batch(4, O.ROSENBROCK, x0, opts=_oracle_opts(O.LBFGS, kw), sum_mode=O.TREE, threads=T, ept=E)
+    assert np.array_equal(x.cpu().numpy().view(np.uint64), o["x"].view(np.uint64))
+    assert np.array_equal(out["iters"].cpu().numpy(), o["iters"]) and np.array_equal(out["nf"].cpu().numpy(), o["nf"])
+    xn = torch.tensor(x0, device=dev)
+    outn = NLO.minimize_rci(4, xn, fun, check_every=1, hess="numerical", **kw)
+    on = O.solve_batch(4, O.ROSENBROCK, x0, opts=_oracle_opts(O.LBFGS, kw), sum_mode=O.TREE, threads=T, ept=E, bfgs_form=4096)
+    assert np.array_equal(xn.cpu().numpy().view(np.uint64), on["x"].view(np.uint64))
+    assert np.array_equal(outn["iters"].cpu().numpy(), on["iters"])
+    assert float((xn - 1.0).abs().max()) < 1e-8
 
 
 def test_augmented_lagrangian_exact_inner_solvers_refuse_n_beyond_2048():
