@@ -396,6 +396,9 @@ def minimize_rci(solver, x, fun, options=None, max_steps=10000000, check_every=8
                                  _ptr(out["nf"]), _ptr(out["ng"])), "fl_rci_results")
         torch.cuda.synchronize()
         out["steps"] = steps
+        if hasattr(FL, "fl_rci_cooperative_groups"):
+            FL.fl_rci_cooperative_groups.argtypes = [_vp]
+            out["cooperative_groups"] = int(FL.fl_rci_cooperative_groups(h))
     finally:
         FL.fl_rci_destroy(h)
     return out

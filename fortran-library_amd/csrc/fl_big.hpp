@@ -31,7 +31,11 @@ template <int OBJ, int METHOD> struct BigSolver {
     // update_form 100 + BF_DEFER); L_STAGE: s_l[j], q_l[j] of BF_FOLD_COLS columns while folding
     static constexpr int BF_DEFER = FL_BFGS_DEFER, BF_FOLD_COLS = 128, BF_MAX_SLOTS = 8, BF_MAX_N = BF_MAX_SLOTS * 2 * T;
     static constexpr int L_STAGE = L_ALPHA + FL_MAX_MEMORY;
-    static constexpr int LDS_TOTAL = L_STAGE + (METHOD == FL_SOLVER_BFGS ? 2 * BF_DEFER * BF_FOLD_COLS + 4 : 0);
+    static constexpr int L_COOP = L_STAGE + (METHOD == FL_SOLVER_BFGS ? 2 * BF_DEFER * BF_FOLD_COLS + 4 : 0);
+    // cooperative form (reverse communication only): the partial sums of up to COOP_MAX_GROUPS workgroups, staged for the
+    // left-to-right addition
+    static constexpr int COOP_MAX_GROUPS = 256;
+    static constexpr int LDS_TOTAL = L_COOP + (OBJ == FL_OBJ_EXTERNAL && METHOD != FL_SOLVER_BFGS ? COOP_MAX_GROUPS * Reducer<16>::NVMAX : 0);
     static constexpr int RCI_SCALARS = 48;
     static constexpr int UNI_LEVEL = (METHOD == FL_SOLVER_BFGS) ? 2 : FL_UNI_LEVEL; // 128 VGPRs per wave: BFGS pins the search to SGPRs
 
@@ -53,11 +57,20 @@ template <int OBJ, int METHOD> struct BigSolver {
     double a_id;
     LineSearch ls;
     enum { PH_INIT = 0, PH_LS = 1, PH_DONE = 2 };
+    // COOPERATIVE form (reverse communication, few problems of very large n): G workgroups share one problem.  Workgroup
+    // wg owns the slots c_lo <= c < c_hi of every thread (a contiguous range of ceil(nslot / G) slots), runs the same
+    // scalar machine as its siblings and meets them in every reduction: each sums its own slots in the usual order
+    // (thread, wave tree, waves left to right), publishes the partial, and all add the G partials left to right -- the
+    // oracle's tree order with `groups` (oracle/fl_oracle.c: tree_reduce).  G = 1: everything as before.
+    int G, wg, c_lo, c_hi;
+    double *coop_part;       // [2][G][NVMAX] partial sums of this problem's workgroups (two generations)
+    unsigned *coop_counter;  // arrivals at this problem's barriers (zeroed by the host before every launch)
+    unsigned coop_gen;
 
     __host__ __device__ static int slots_for(int n) { return ((n + 1) / 2 + T - 1) / T; }
 
-    __device__ __forceinline__ BigSolver(const SolveArgs &A_, double *lds_, double *rows_all)
-        : A(A_), lds(lds_), prob(blockIdx.x), n(A_.n), tid(threadIdx.x), R{lds_ + L_RED, 0}
+    __device__ __forceinline__ BigSolver(const SolveArgs &A_, double *lds_, double *rows_all, int problem = -1)
+        : A(A_), lds(lds_), prob(problem >= 0 ? problem : (int)blockIdx.x), n(A_.n), tid(threadIdx.x), R{lds_ + L_RED, 0}
     {
         nslot = slots_for(n);
         npad = (size_t)nslot * T * 2;
@@ -73,6 +86,77 @@ template <int OBJ, int METHOD> struct BigSolver {
         hist = nullptr;
         if constexpr (METHOD == FL_SOLVER_LBFGS) hist = A.hist + (size_t)prob * (size_t)(2 * A.mem) * npad;
         if constexpr (METHOD == FL_SOLVER_BFGS) hist = A.hist + (size_t)prob * bfgs_rows(n) * npad; // H, pending s_l q_l, y
+        G = 1;
+        wg = 0;
+        c_lo = 0;
+        c_hi = nslot;
+        coop_part = nullptr;
+        coop_counter = nullptr;
+        coop_gen = 0;
+    }
+    __host__ __device__ static int coop_slots_per_group(int n, int groups) { return (slots_for(n) + groups - 1) / groups; }
+    // the number of workgroups that really share a problem when `groups` are asked for (no empty ones)
+    __host__ __device__ static int coop_groups(int n, int groups)
+    {
+        if (groups <= 1) return 1;
+        const int per = coop_slots_per_group(n, groups);
+        return (slots_for(n) + per - 1) / per;
+    }
+    __device__ __forceinline__ void set_cooperative(int groups, int group, double *part, unsigned *counter)
+    {
+        G = groups;
+        wg = group;
+        const int per = (nslot + groups - 1) / groups;
+        c_lo = group * per;
+        c_hi = c_lo + per < nslot ? c_lo + per : nslot;
+        coop_part = part;
+        coop_counter = counter;
+    }
+    // Every workgroup of the problem has arrived.  What crosses workgroups -- the partial sums and this counter -- moves by
+    // device-scope atomics (they bypass the XCDs' private L2s); vector elements never cross (each is touched by its owner
+    // alone, and a kernel boundary lies between two steps).  So the ordering needs no device-wide fence -- a
+    // __threadfence() here writes the whole XCD's dirty L2 back: measured ~60 us per barrier -- only that thread 0's
+    // partial-sum stores have completed before its arrival is counted (workgroup-scope release = wait for the stores).
+    __device__ __forceinline__ void coop_barrier()
+    {
+        __syncthreads();
+        ++coop_gen; // (every thread counts the barriers: the generation picks the partial sums' buffer in reduce())
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __hip_atomic_fetch_add(coop_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned want = coop_gen * (unsigned)G;
+            while (__hip_atomic_load(coop_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        __syncthreads();
+    }
+    template <int NV> __device__ __forceinline__ void reduce(double (&v)[NV])
+    {
+        R.run(v);
+        if (G == 1) return;
+        double *mine = coop_part + ((size_t)(coop_gen & 1) * G + wg) * Reducer<NW>::NVMAX;
+        if (tid == 0) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) __hip_atomic_store(mine + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const double *all = coop_part + (size_t)(coop_gen & 1) * G * Reducer<NW>::NVMAX;
+        coop_barrier(); // (advances coop_gen: `all` was taken before)
+        // thread w fetches workgroup w's partial sums (G loads in flight at once: one after the other they cost a trip to
+        // memory each), then everybody adds them left to right from LDS
+        double *stage = lds + L_COOP;
+        if (tid < G) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                stage[tid * NV + i] = __hip_atomic_load(all + (size_t)tid * Reducer<NW>::NVMAX + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            double t = stage[i];
+            for (int w = 1; w < G; ++w) t = t + stage[w * NV + i];
+            v[i] = t;
+        }
+        __syncthreads(); // (the stage is free again)
     }
     __host__ __device__ static size_t bfgs_rows(int n) { return (size_t)n + 2 * BF_DEFER + 1; }
 
@@ -114,9 +198,9 @@ template <int OBJ, int METHOD> struct BigSolver {
         *reinterpret_cast<double2 *>(row + e) = make_double2(u, v);
     }
     // running sum in the register path's order: first term of the thread starts it
-    __device__ __forceinline__ static void acc2(double &s, int c, double ta, double tb)
+    __device__ __forceinline__ void acc2(double &s, int c, double ta, double tb) const
     {
-        s = (c == 0) ? ta : s + ta;
+        s = (c == c_lo) ? ta : s + ta;
         s = s + tb;
     }
 
@@ -136,7 +220,7 @@ template <int OBJ, int METHOD> struct BigSolver {
     }
     __device__ __forceinline__ void clear_rows() // first launch: p = 0 like the register path, padding defined
     {
-        for (int c = 0; c < nslot; ++c) {
+        for (int c = c_lo; c < c_hi; ++c) {
             const int e = e_of(c);
             stw(p, e, 0.0, 0.0);
             stw(x0, e, 0.0, 0.0);
@@ -154,7 +238,7 @@ template <int OBJ, int METHOD> struct BigSolver {
     // ---------------------------------------------------------------- evaluation
     __device__ __forceinline__ void move(double at)
     {
-        for (int c = 0; c < nslot; ++c) {
+        for (int c = c_lo; c < c_hi; ++c) {
             const int e = e_of(c);
             double xa, xb, pa, pb;
             ldw(x0, e, xa, xb);
@@ -167,7 +251,7 @@ template <int OBJ, int METHOD> struct BigSolver {
     {
         if constexpr (OBJ == FL_OBJ_ROSENBROCK) __syncthreads(); // neighbours' x are written
         double r[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int c = 0; c < nslot; ++c) {
+        for (int c = c_lo; c < c_hi; ++c) {
             const int e = e_of(c);
             double xa, xb, ga, gb, ta, tb, ua = 0.0, ub = 0.0;
             ldu(x, e, xa, xb);
@@ -219,7 +303,7 @@ template <int OBJ, int METHOD> struct BigSolver {
             acc2(r[2], c, ga * pa, gb * pb);
             acc2(r[3], c, ga * ga, gb * gb);
         }
-        R.run(r);
+        reduce(r);
         f = uni(Objective<OBJ, 1, 2>::combine(r[0], r[1]));
         gp = uni(r[2]);
         ggo = uni(r[3]);
@@ -231,7 +315,7 @@ template <int OBJ, int METHOD> struct BigSolver {
     {
         if constexpr (OBJ == FL_OBJ_ROSENBROCK) __syncthreads(); // x0 / p rows of the neighbours are complete
         double r[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int c = 0; c < nslot; ++c) {
+        for (int c = c_lo; c < c_hi; ++c) {
             const int e = e_of(c);
             double oa, ob, pa, pb, ga, gb, ta, tb, ua = 0.0, ub = 0.0;
             ldw(x0, e, oa, ob);
@@ -284,7 +368,7 @@ template <int OBJ, int METHOD> struct BigSolver {
             acc2(r[2], c, ga * pa, gb * pb);
             acc2(r[3], c, ga * ga, gb * gb);
         }
-        R.run(r);
+        reduce(r);
         f = uni(Objective<OBJ, 1, 2>::combine(r[0], r[1]));
         gp = uni(r[2]);
         ggo = uni(r[3]);
@@ -293,7 +377,7 @@ template <int OBJ, int METHOD> struct BigSolver {
     __device__ __forceinline__ void take_gradient(const double *g_user, double &gp, double &ggo)
     {
         double r[2] = {0.0, 0.0};
-        for (int c = 0; c < nslot; ++c) {
+        for (int c = c_lo; c < c_hi; ++c) {
             const int e = e_of(c);
             double ga, gb, pa, pb;
             ldu(g_user, e, ga, gb);
@@ -302,7 +386,7 @@ template <int OBJ, int METHOD> struct BigSolver {
             acc2(r[0], c, ga * pa, gb * pb);
             acc2(r[1], c, ga * ga, gb * gb);
         }
-        R.run(r);
+        reduce(r);
         gp = uni(r[0]);
         ggo = uni(r[1]);
     }
@@ -338,7 +422,7 @@ template <int OBJ, int METHOD> struct BigSolver {
     }
     __device__ __forceinline__ void neg_gradient_direction() // p=-fdnew
     {
-        for (int c = 0; c < nslot; ++c) {
+        for (int c = c_lo; c < c_hi; ++c) {
             const int e = e_of(c);
             double ga, gb;
             ldw(g, e, ga, gb);
@@ -359,7 +443,7 @@ template <int OBJ, int METHOD> struct BigSolver {
             }
             fused = fused && h_valid;
         }
-        for (int c = 0; c < nslot; ++c) { // xold=x; fdold=fdnew
+        for (int c = c_lo; c < c_hi; ++c) { // xold=x; fdold=fdnew
             const int e = e_of(c);
             double u, v;
             ldu(x, e, u, v);
@@ -432,7 +516,7 @@ template <int OBJ, int METHOD> struct BigSolver {
         double beta;
         if (A.cg_method == FL_CG_DY) { // NO.f90:366
             double q[1] = {0.0};
-            for (int c = 0; c < nslot; ++c) {
+            for (int c = c_lo; c < c_hi; ++c) {
                 const int e = e_of(c);
                 double ga, gb, oa, ob, pa, pb;
                 ldw(g, e, ga, gb);
@@ -440,11 +524,11 @@ template <int OBJ, int METHOD> struct BigSolver {
                 ldw(p, e, pa, pb);
                 acc2(q[0], c, (ga - oa) * pa, (gb - ob) * pb);
             }
-            R.run(q);
+            reduce(q);
             beta = gg / q[0];
         } else { // NO.f90:387
             double q[2] = {0.0, 0.0};
-            for (int c = 0; c < nslot; ++c) {
+            for (int c = c_lo; c < c_hi; ++c) {
                 const int e = e_of(c);
                 double ga, gb, oa, ob;
                 ldw(g, e, ga, gb);
@@ -452,11 +536,11 @@ template <int OBJ, int METHOD> struct BigSolver {
                 acc2(q[0], c, ga * (ga - oa), gb * (gb - ob));
                 acc2(q[1], c, oa * oa, ob * ob);
             }
-            R.run(q);
+            reduce(q);
             beta = q[0] / q[1];
         }
         double q2[2] = {0.0, 0.0};
-        for (int c = 0; c < nslot; ++c) {
+        for (int c = c_lo; c < c_hi; ++c) {
             const int e = e_of(c);
             double ga, gb, pa, pb;
             ldw(g, e, ga, gb);
@@ -467,7 +551,7 @@ template <int OBJ, int METHOD> struct BigSolver {
             acc2(q2[0], c, ga * pa, gb * pb);
             acc2(q2[1], c, pa * pa, pb * pb);
         }
-        R.run(q2);
+        reduce(q2);
         phid = q2[0];
         pp = q2[1];
         if (phid > 0.0) { // NO.f90:368-370
@@ -493,7 +577,7 @@ template <int OBJ, int METHOD> struct BigSolver {
         double r[3] = {0.0, 0.0, 0.0};
         {
             double *s0 = srow(0), *y0 = s0 + npad;
-            for (int c = 0; c < nslot; ++c) {
+            for (int c = c_lo; c < c_hi; ++c) {
                 const int e = e_of(c);
                 double xa, xb, oa, ob, ga, gb, ha, hb;
                 ldu(x, e, xa, xb);
@@ -508,7 +592,7 @@ template <int OBJ, int METHOD> struct BigSolver {
                 acc2(r[2], c, sa * ga, sb * gb);
             }
         }
-        R.run(r);
+        reduce(r);
         if (tid == 0) rho_s[recent] = 1.0 / r[0];
         rho_recent = uni(1.0 / r[0]);
         yy_recent = uni(r[1]);
@@ -521,7 +605,7 @@ template <int OBJ, int METHOD> struct BigSolver {
             const double *nxt = last ? yj : srow(j + 1); // last: the first dot of the way up is y_{cnt-1}.p
             const double *src = (j == 0) ? g : p;
             double q[1] = {0.0};
-            for (int c = 0; c < nslot; ++c) {
+            for (int c = c_lo; c < c_hi; ++c) {
                 const int e = e_of(c);
                 double pa, pb, ya, yb, na, nb;
                 ldw(src, e, pa, pb);
@@ -539,7 +623,7 @@ template <int OBJ, int METHOD> struct BigSolver {
                 stw(p, e, pa, pb);
                 acc2(q[0], c, na * pa, nb * pb);
             }
-            R.run(q);
+            reduce(q);
             if (!last) {
                 const int sl = slot_of(j + 1);
                 al = rho_s[sl] * q[0];
@@ -559,7 +643,7 @@ template <int OBJ, int METHOD> struct BigSolver {
             const double *nxt = last ? g : srow(j - 1) + npad;
             double q[1] = {0.0};
             rr[0] = rr[1] = 0.0;
-            for (int c = 0; c < nslot; ++c) {
+            for (int c = c_lo; c < c_hi; ++c) {
                 const int e = e_of(c);
                 double pa, pb, sa, sb, na, nb;
                 ldw(p, e, pa, pb);
@@ -578,9 +662,9 @@ template <int OBJ, int METHOD> struct BigSolver {
                 stw(p, e, pa, pb);
             }
             if (last) {
-                R.run(rr);
+                reduce(rr);
             } else {
-                R.run(q);
+                reduce(q);
                 ydotp = q[0];
             }
         }
@@ -597,7 +681,7 @@ template <int OBJ, int METHOD> struct BigSolver {
         double *drho = lds + L_RHO, *dcs = drho + BF_DEFER; // rho_l, cs_l of the pending updates
         // s, y (y also as a row: the matvec reads y_j per column)
         double r1[1] = {0.0};
-        for (int c = 0; c < nslot; ++c) {
+        for (int c = c_lo; c < c_hi; ++c) {
             const int e = e_of(c);
             double xa, xb, oa, ob, ga, gb, ha, hb;
             ldu(x, e, xa, xb);
@@ -608,7 +692,7 @@ template <int OBJ, int METHOD> struct BigSolver {
             stw(yrow, e, ya, yb);
             acc2(r1[0], c, ya * (xa - oa), yb * (xb - ob));
         }
-        R.run(r1);
+        reduce(r1);
         const double rho = uni(1.0 / r1[0]);
         if (!h_valid) {
             ndef = 0;
@@ -621,7 +705,7 @@ template <int OBJ, int METHOD> struct BigSolver {
         // loads spilled 240-310 VGPRs (1200 in the reverse-communication kernel).
         double *Sn = def_row(2 * ndef), *Qn = def_row(2 * ndef + 1), *wrow = p;
         if (h_ident) {
-            for (int c = 0; c < nslot; ++c) {
+            for (int c = c_lo; c < c_hi; ++c) {
                 const int e = e_of(c);
                 double ya, yb, ga, gb;
                 ldw(yrow, e, ya, yb);
@@ -675,7 +759,7 @@ template <int OBJ, int METHOD> struct BigSolver {
         for (int l = 0; l < ndef; ++l) { // corrections of the pending updates, oldest first
             const double *S = def_row(2 * l), *Q = def_row(2 * l + 1);
             double r[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int c = 0; c < nslot; ++c) {
+            for (int c = c_lo; c < c_hi; ++c) {
                 const int e = e_of(c);
                 double sa, sb, qa, qb, ya, yb, ga, gb;
                 ldw(S, e, sa, sb);
@@ -687,9 +771,9 @@ template <int OBJ, int METHOD> struct BigSolver {
                 acc2(r[2], c, sa * ga, sb * gb);
                 acc2(r[3], c, qa * ga, qb * gb);
             }
-            R.run(r);
+            reduce(r);
             const double rl = drho[l], cl = dcs[l];
-            for (int c = 0; c < nslot; ++c) {
+            for (int c = c_lo; c < c_hi; ++c) {
                 const int e = e_of(c);
                 double sa, sb, qa, qb, q0, q1, w0, w1;
                 ldw(S, e, sa, sb);
@@ -702,7 +786,7 @@ template <int OBJ, int METHOD> struct BigSolver {
             }
         }
         double r3[3] = {0.0, 0.0, 0.0};
-        for (int c = 0; c < nslot; ++c) {
+        for (int c = c_lo; c < c_hi; ++c) {
             const int e = e_of(c);
             double ya, yb, ga, gb, xa, xb, oa, ob, q0, q1;
             ldw(yrow, e, ya, yb);
@@ -714,10 +798,10 @@ template <int OBJ, int METHOD> struct BigSolver {
             acc2(r3[1], c, (xa - oa) * ga, (xb - ob) * gb);
             acc2(r3[2], c, q0 * ga, q1 * gb);
         }
-        R.run(r3);
+        reduce(r3);
         const double cs = uni(rho * rho * r3[0] + rho);
         double r4[2] = {0.0, 0.0};
-        for (int c = 0; c < nslot; ++c) {
+        for (int c = c_lo; c < c_hi; ++c) {
             const int e = e_of(c);
             double ga, gb, xa, xb, oa, ob, q0, q1, w0, w1;
             ldw(g, e, ga, gb);
@@ -738,7 +822,7 @@ template <int OBJ, int METHOD> struct BigSolver {
             dcs[ndef] = cs;
         }
         ++ndef;
-        R.run(r4); // (its barrier also publishes rho_l, cs_l and the new rows)
+        reduce(r4); // (its barrier also publishes rho_l, cs_l and the new rows)
         phid = uni(r4[0]); // finished -- two scalars -- before the fold: left pending, the reduction's 32 partial sums
         pp = uni(r4[1]);   // stay in vector registers across it
         a = 1.0;
@@ -794,6 +878,7 @@ template <int OBJ, int METHOD> struct BigSolver {
     // (ownership rules of the parked state: fl_device.hpp, above Solver::save -- rule 3 is the barrier that ends load())
     __device__ __forceinline__ void save(double *sc, double *rho, double fv_c, double pv_c)
     {
+        if (wg != 0) return; // cooperative form: every workgroup holds the same scalars; the first one parks them
         if constexpr (METHOD == FL_SOLVER_LBFGS || METHOD == FL_SOLVER_BFGS) { // rho ring / rho_l, cs_l of pending updates
             __syncthreads();
             if (tid < FL_MAX_MEMORY) rho[tid] = lds[L_RHO + tid];
@@ -833,7 +918,9 @@ template <int OBJ, int METHOD> struct BigSolver {
         a_id = sc[29];
         pin_scalars();
         // every wave has read the parked scalars before thread 0 may overwrite them in save(): a step that only
-        // takes an objective value has no other barrier
+        // takes an objective value has no other barrier (cooperative form: every workgroup of the problem has)
+        // (cooperative form: the step writes the OTHER copy of the parked state -- rci_step_big_kernel -- so there is
+        // nothing to protect across workgroups)
         __syncthreads();
     }
 
@@ -855,7 +942,7 @@ template <int OBJ, int METHOD> struct BigSolver {
 
     __device__ __forceinline__ void finish() // x already holds the last evaluated point
     {
-        if (tid == 0) {
+        if (tid == 0 && wg == 0) {
             if (A.f_out) A.f_out[prob] = fnew;
             if (A.gg_out) A.gg_out[prob] = gg;
             if (A.iters) A.iters[prob] = iters;

@@ -19,6 +19,7 @@
 #include "fl_big.hpp"
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <string>
@@ -112,17 +113,27 @@ __global__ __launch_bounds__(NW * 64) void rci_step_kernel(SolveArgs A, int firs
 }
 
 // n > 4096 (fl_big.hpp): the same step with the machine's vectors in HBM, one workgroup of 1024 threads per problem
+// groups > 1: the COOPERATIVE form -- `groups` workgroups share one problem (BigSolver::set_cooperative): blockIdx.x =
+// problem * groups + group.  For few problems of very large n (the reference's callers typically solve ONE problem of
+// any dim): a single n = 2^20 problem then occupies the whole chip instead of one CU.
 template <int METHOD>
 __global__ __launch_bounds__(1024) void rci_step_big_kernel(SolveArgs A, int first, double *sc_all, double *vec_all,
                                                             double *rho_all, const double *f_dev, const double *g_dev,
-                                                            int32_t *request)
+                                                            int32_t *request, int groups, double *coop_part,
+                                                            unsigned *coop_counter, int parity)
 {
     using S = BigSolver<FL_OBJ_EXTERNAL, METHOD>;
     __shared__ __attribute__((aligned(16))) double lds[S::LDS_TOTAL];
-    S s(A, lds, vec_all);
-    const int prob = blockIdx.x, n = A.n;
-    double *sc = sc_all + (size_t)prob * S::RCI_SCALARS;
-    double *rho = rho_all + (size_t)prob * FL_MAX_MEMORY;
+    const int prob = blockIdx.x / groups, group = blockIdx.x - prob * groups, n = A.n;
+    S s(A, lds, vec_all, prob);
+    if (groups > 1)
+        s.set_cooperative(groups, group, coop_part + (size_t)prob * 2 * groups * Reducer<S::NW>::NVMAX, coop_counter + prob);
+    // cooperative form: the scalars (and the rho ring) are parked in two copies used alternately -- this step reads copy
+    // `parity` and its first workgroup writes the other one, so no workgroup can see a half-written block and no barrier
+    // is needed between load() and save() (a step that only takes an objective value has none of its own)
+    const size_t two = groups > 1 ? 2 : 1, in = groups > 1 ? (size_t)parity : 0, out = groups > 1 ? (size_t)(1 - parity) : 0;
+    const double *sc_in = sc_all + ((size_t)prob * two + in) * S::RCI_SCALARS, *rho_in = rho_all + ((size_t)prob * two + in) * FL_MAX_MEMORY;
+    double *sc = sc_all + ((size_t)prob * two + out) * S::RCI_SCALARS, *rho = rho_all + ((size_t)prob * two + out) * FL_MAX_MEMORY;
     s.init();
     int rq;
     double fv = 0.0, pv = 0.0;
@@ -130,9 +141,10 @@ __global__ __launch_bounds__(1024) void rci_step_big_kernel(SolveArgs A, int fir
         s.clear_rows();
         rq = s.start();
     } else {
-        s.load(sc, rho, fv, pv);
+        s.load(sc_in, rho_in, fv, pv);
         if (s.phase == S::PH_DONE) {
-            if (threadIdx.x == 0) request[prob] = 0;
+            if (group == 0) s.save(sc, rho, fv, pv); // (the other copy must say so too)
+            if (threadIdx.x == 0 && group == 0) request[prob] = 0;
             return;
         }
         double ggv = s.gg;
@@ -143,7 +155,7 @@ __global__ __launch_bounds__(1024) void rci_step_big_kernel(SolveArgs A, int fir
     if (rq == 0) s.finish();
     else if (!(rq & (FL_REQ_SAME | FL_REQ_NOMOVE))) s.move(s.request_point());
     s.save(sc, rho, fv, pv);
-    if (threadIdx.x == 0) request[prob] = rq;
+    if (threadIdx.x == 0 && group == 0) request[prob] = rq;
 }
 
 // ------------------------------------------------------------------ the line searchers on their own
@@ -270,6 +282,10 @@ struct Rci {
     double *sc, *vec, *rho, *ws, *f_out, *gg_out;
     int32_t *iters, *status, *nf, *ng;
     hipStream_t stream;
+    int coop_groups;        // vectors-in-HBM path: workgroups per problem (BigSolver's cooperative form), 1 = none
+    int parity;             // ... which copy of the parked scalars the next step reads
+    double *coop_part;      // [batch][2][groups][NVMAX]
+    unsigned *coop_counter; // [batch]
 };
 
 template <int NW, int EPT>
@@ -307,10 +323,12 @@ static void launch_rci(Rci *h, const double *f, const double *g, const double *c
 
 static void launch_rci_big(Rci *h, const double *f, const double *g, int32_t *req)
 {
-    dim3 grid(h->batch), block(1024);
+    const int G = h->coop_groups > 1 ? h->coop_groups : 1;
+    if (G > 1) (void)hipMemsetAsync(h->coop_counter, 0, sizeof(unsigned) * h->batch, h->stream); // this launch's barriers count from 0
+    dim3 grid(h->batch * G), block(1024);
 #define FL_RCI(M)                                                                                                 \
     hipLaunchKernelGGL((rci_step_big_kernel<M>), grid, block, 0, h->stream, h->A, h->first, h->sc, h->vec, h->rho, f, \
-                       g, req)
+                       g, req, G, h->coop_part, h->coop_counter, h->parity)
     switch (h->solver) {
     case FL_SOLVER_SD: FL_RCI(FL_SOLVER_SD); break;
     case FL_SOLVER_CG: FL_RCI(FL_SOLVER_CG); break;
@@ -318,6 +336,7 @@ static void launch_rci_big(Rci *h, const double *f, const double *g, int32_t *re
     default: FL_RCI(FL_SOLVER_LBFGS); break;
     }
 #undef FL_RCI
+    if (G > 1) h->parity ^= 1;
 }
 
 } // namespace fl
@@ -331,6 +350,8 @@ struct fl_rci {
 int fl_rci_destroy(fl_rci *h)
 {
     if (!h) return FL_OK;
+    if (h->r.coop_part) (void)hipFree(h->r.coop_part);
+    if (h->r.coop_counter) (void)hipFree(h->r.coop_counter);
     void *bufs[] = {h->r.sc, h->r.vec, h->r.rho, h->r.ws, h->r.f_out, h->r.gg_out, h->r.iters, h->r.status,
                     h->r.nf, h->r.ng, h->r.outer, h->r.cnorm2};
     for (void *b : bufs)
@@ -393,9 +414,9 @@ int fl_rci_create(fl_rci **out, int solver, int batch, int n, const fl_options *
     A.precision = opt->precision;
     const size_t npad = (size_t)threads * ept, B = (size_t)batch;
     const size_t wsb = fl_workspace_bytes_for(solver, batch, n, opt);
-    bool ok = hipMalloc((void **)&r.sc, B * 48 * sizeof(double)) == hipSuccess &&
+    bool ok = hipMalloc((void **)&r.sc, 2 * B * 48 * sizeof(double)) == hipSuccess && // (two copies: the cooperative form alternates)
               hipMalloc((void **)&r.vec, B * 4 * npad * sizeof(double)) == hipSuccess &&
-              hipMalloc((void **)&r.rho, B * FL_MAX_MEMORY * sizeof(double)) == hipSuccess &&
+              hipMalloc((void **)&r.rho, 2 * B * FL_MAX_MEMORY * sizeof(double)) == hipSuccess &&
               hipMalloc((void **)&r.f_out, B * sizeof(double)) == hipSuccess &&
               hipMalloc((void **)&r.gg_out, B * sizeof(double)) == hipSuccess &&
               hipMalloc((void **)&r.iters, B * sizeof(int32_t)) == hipSuccess &&
@@ -403,6 +424,23 @@ int fl_rci_create(fl_rci **out, int solver, int batch, int n, const fl_options *
               hipMalloc((void **)&r.nf, B * sizeof(int32_t)) == hipSuccess &&
               hipMalloc((void **)&r.ng, B * sizeof(int32_t)) == hipSuccess;
     if (ok && wsb) ok = hipMalloc((void **)&r.ws, wsb) == hipSuccess;
+    r.coop_groups = 1;
+    if (ok && threads == 1024 && solver != FL_SOLVER_BFGS) {
+        // Few problems of very large n: several workgroups per problem, as many as keep every workgroup RESIDENT (their
+        // barriers spin: one 1024-thread workgroup per CU is assumed, 256 CUs) and give each at least two slots.
+        // FL_COOP_GROUPS in the environment overrides (tests; 1 switches the cooperative form off).
+        using BS = fl::BigSolver<FL_OBJ_EXTERNAL, FL_SOLVER_LBFGS>;
+        int want = 256 / batch;
+        const int nslot = BS::slots_for(n);
+        if (want > nslot / 2) want = nslot / 2;
+        if (const char *e = std::getenv("FL_COOP_GROUPS")) want = std::atoi(e);
+        if (want > 256 / batch) want = 256 / batch;
+        if (want > 1) {
+            r.coop_groups = BS::coop_groups(n, want);
+            ok = hipMalloc((void **)&r.coop_part, B * 2 * r.coop_groups * fl::Reducer<16>::NVMAX * sizeof(double)) == hipSuccess &&
+                 hipMalloc((void **)&r.coop_counter, B * sizeof(unsigned)) == hipSuccess;
+        }
+    }
     if (!ok) {
         fl_rci_destroy(h);
         return FL_ERR_WORKSPACE;
@@ -526,6 +564,10 @@ int fl_rci_results_auglag(fl_rci *h, double *cnorm2_dev, int32_t *outer_dev)
     if (outer_dev) ok &= hipMemcpyAsync(outer_dev, h->r.outer, B * 4, hipMemcpyDeviceToDevice, h->r.stream) == hipSuccess;
     return ok ? FL_OK : FL_ERR_LAUNCH;
 }
+
+// workgroups that share one problem in this handle's step kernel (> 1: the cooperative form of the vectors-in-HBM path;
+// the summation order -- hence the bits -- depends on it: oracle flo_set_sum_groups)
+int fl_rci_cooperative_groups(fl_rci *h) { return h ? (h->r.coop_groups > 1 ? h->r.coop_groups : 1) : 0; }
 
 int fl_rci_hessian_buffer(fl_rci *h, double **hessian_dev, int *ld)
 {

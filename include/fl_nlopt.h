@@ -281,6 +281,12 @@ int fl_multi_solve(int solver, int objective, int batch, int n, double *x_host, 
 typedef struct fl_rci fl_rci;
 int fl_rci_create(fl_rci **handle, int solver, int batch, int n, const fl_options *opt, void *stream);
 int fl_rci_hessian_buffer(fl_rci *handle, double **hessian_dev, int *ld);
+/* n > 4096 with few problems (batch < 128): the step kernel runs COOPERATIVELY -- several workgroups share one problem
+ * (each owns a range of the vector, all run the same scalar machine and meet in every reduction), as many as stay resident
+ * together (256 / batch) -- so that ONE problem of n = 10^6 occupies the chip instead of one CU.  The number in use (1 = not
+ * cooperative); sums are then taken per workgroup and added left to right (bit-reproducible; oracle: flo_set_sum_groups).
+ * FL_COOP_GROUPS in the environment at fl_rci_create overrides the choice (1 = off). */
+int fl_rci_cooperative_groups(fl_rci *handle);
 int fl_rci_step(fl_rci *handle, double *x_dev, const double *f_dev, const double *g_dev, int32_t *request_dev);
 /* The same step with flags (FL_SOLVER_SD | CG | LBFGS).  FL_RCI_BOTH: the caller evaluated f AND grad f at every requested point, whatever the bits
  * asked for (the natural form of a torch / HIP objective, the reference's f_fd).  The kernel then answers a request for the

@@ -36,20 +36,27 @@ int flo_get_sum_mode(void) { return g_mode; }
  * dealt round-robin over the threads -- the HIP kernels' coalesced layout */
 static inline int elem_of(int t, int k, int T) { return (((k >> 1) * T + t) << 1) + (k & 1); }
 
-static double tree_reduce(int n, const double *a, const double *b)
+/* groups > 1 (the cooperative form of the vectors-in-HBM kernels, csrc/fl_big.hpp): `groups` workgroups share one
+ * problem; workgroup w owns the register slots [w*per, (w+1)*per) of every thread, per = ceil(slots / groups), sums them in
+ * the usual order (thread, wave tree, waves left to right), and the workgroups' partial sums are added left to right.
+ * A process-wide setting (flo_set_sum_groups), read by every summation in FLO_SUM_TREE mode. */
+static int g_groups = 1;
+void flo_set_sum_groups(int groups) { g_groups = groups > 1 ? groups : 1; }
+
+static double tree_reduce_range(int n, const double *a, const double *b, int k_lo, int k_hi)
 {
-    const int T = g_threads, E = g_ept, NW = T / 64;
+    const int T = g_threads, NW = T / 64;
     double wave[64]; /* up to 16 waves */
     double lane[64], tmp[64];
     for (int w = 0; w < NW; ++w) {
         for (int l = 0; l < 64; ++l) {
             const int t = w * 64 + l;
             double acc = 0.0;
-            for (int k = 0; k < E; ++k) {
+            for (int k = k_lo; k < k_hi; ++k) {
                 const int e = elem_of(t, k, T);
                 double term = 0.0;
                 if (e < n) term = b ? a[e] * b[e] : a[e];
-                acc = (k == 0) ? term : acc + term;
+                acc = (k == k_lo) ? term : acc + term;
             }
             lane[l] = acc;
         }
@@ -64,6 +71,19 @@ static double tree_reduce(int n, const double *a, const double *b)
     }
     double tot = wave[0];
     for (int w = 1; w < NW; ++w) tot = tot + wave[w];
+    return tot;
+}
+static double tree_reduce(int n, const double *a, const double *b)
+{
+    const int E = g_ept;
+    if (g_groups <= 1) return tree_reduce_range(n, a, b, 0, E);
+    const int slots = E / 2, per = (slots + g_groups - 1) / g_groups;
+    double tot = 0.0;
+    for (int w = 0; w * per < slots; ++w) {
+        const int c_hi = (w + 1) * per < slots ? (w + 1) * per : slots;
+        const double part = tree_reduce_range(n, a, b, 2 * w * per, 2 * c_hi);
+        tot = (w == 0) ? part : tot + part;
+    }
     return tot;
 }
 

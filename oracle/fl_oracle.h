@@ -44,6 +44,7 @@ enum { FLO_SUM_SEQ = 0, FLO_SUM_TREE = 1 };
 /* thread-local: summation mode and GPU reduction geometry (threads per problem,
  * elements per thread) used by FLO_SUM_TREE */
 void flo_set_sum_mode(int mode, int threads, int ept);
+void flo_set_sum_groups(int groups); /* FLO_SUM_TREE: workgroups sharing one problem (cooperative vectors-in-HBM kernels); process-wide */
 double flo_dot(int n, const double *a, const double *b);
 double flo_tree_sum(int n, const double *term);
 

@@ -247,6 +247,58 @@ def test_rci_full_and_compact_modes_walk_the_same_path_in_fewer_rounds(solver_na
     assert len(seen["epochs"]) > 1 and seen["rows"] < 0.8 * B * c["steps"]  # the tail is evaluated for the running problems only
 
 
+@pytest.mark.parametrize("solver_name,n,groups", [("LBFGS", 10000, 4), ("CG", 10000, 4), ("LBFGS", 20001, 8), ("SD", 9000, 2)])
+def test_cooperative_large_n_solve_bitexact(solver_name, n, groups, monkeypatch):
+    """n > 4096 with few problems: several workgroups share ONE problem (BigSolver's cooperative form, FL_COOP_GROUPS):
+    each owns a range of the vector, all run the same scalar machine and meet in every reduction through device-scope
+    counters.  Sums are taken per workgroup and added left to right -- the oracle's tree order with `groups` -- so the
+    minimiser, iteration and evaluation counts equal the oracle's bit for bit; with one workgroup per problem the bits
+    are those of the plain path."""
+    import FortranLibrary.NonlinearOptimization as NLO
+    dev = torch.device("cuda:0")
+    B = 2
+    rng = np.random.default_rng(n)
+    kappa = np.array([30.0, 200.0])
+    d = 1.0 + (kappa[:, None] - 1.0) * (np.arange(n) / (n - 1))[None, :]
+    b = rng.uniform(-1, 1, (B, n))
+    solver = {"LBFGS": NLO.LBFGS_, "CG": NLO.CG, "SD": NLO.SD}[solver_name]
+    osolver = {"LBFGS": O.LBFGS, "CG": O.CG, "SD": O.SD}[solver_name]
+    kw = dict(Precision=1e-6, MaxIteration=40 if solver_name == "SD" else 300)
+    T, E = NLO.reduction_geometry(n)
+    lib = O.lib()
+    dp = C.POINTER(C.c_double)
+    lib.flo_prob_eval_batch.argtypes = [C.c_int] * 4 + [dp, dp, dp] + [C.c_int] * 4 + [dp] * 4
+    P = lambda a: a.ctypes.data_as(dp)
+    f_h, g_h = np.zeros(B), np.zeros((B, n))
+
+    def fun(xdev):  # the caller's objective, in the summation order of the run at hand (lib.flo_set_sum_groups)
+        xh = np.ascontiguousarray(xdev.cpu().numpy())
+        lib.flo_prob_eval_batch(O.DIAGQUAD, B, n, 0, P(xh), P(d), P(b), O.TREE, T, E, 1, P(f_h), P(g_h), None, None)
+        return torch.tensor(f_h, device=dev), torch.tensor(g_h, device=dev)
+    oo = O.defaults(precision=1e-6, maxit=kw["MaxIteration"], c2=0.45 if solver_name == "CG" else 0.9)
+    res = {}
+    for want in (groups, 1):
+        monkeypatch.setenv("FL_COOP_GROUPS", str(want))
+        x = torch.zeros(B, n, dtype=torch.float64, device=dev)
+        lib.flo_set_sum_groups(1)
+        # (the handle reports how many workgroups really share a problem: no empty ones)
+        probe = NLO.minimize_rci(solver, x, fun, max_steps=0, **kw)
+        G = probe["cooperative_groups"]
+        assert (G > 1) == (want > 1)
+        lib.flo_set_sum_groups(G)
+        try:
+            x = torch.zeros(B, n, dtype=torch.float64, device=dev)
+            out = NLO.minimize_rci(solver, x, fun, check_every=1, **kw)
+            o = O.solve_batch(osolver, O.DIAGQUAD, np.zeros((B, n)), d=d, b=b, opts=oo, sum_mode=O.TREE, threads=T, ept=E, nthreads=1)
+        finally:
+            lib.flo_set_sum_groups(1)
+        assert np.array_equal(x.cpu().numpy().view(np.uint64), o["x"].view(np.uint64)), want
+        assert np.array_equal(out["iters"].cpu().numpy(), o["iters"]) and np.array_equal(out["nf"].cpu().numpy(), o["nf"])
+        assert np.array_equal(out["ng"].cpu().numpy(), o["ng"]) and int(o["iters"].min()) > 3
+        res[want] = x.cpu().numpy()
+    assert np.abs(res[groups] - res[1]).max() < 1e-6  # same minimiser, different (each reproducible) summation orders
+
+
 def test_fortran_use_fortranlibrary_smoke():
     """`use FortranLibrary` from Fortran (amdflang): the shim module forwards to libFL.so, the solver runs on the
     GPU and calls the Fortran callbacks on the host.  Mirrors test/test.f90:330-413: residuals close to 0."""

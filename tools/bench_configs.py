@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--c4-iterations", type=int, default=20)
     ap.add_argument("--c5-batch", type=int, default=8192)
     ap.add_argument("--rci-batch", type=int, default=16384)
+    ap.add_argument("--coop-iterations", type=int, default=60)
     ap.add_argument("--rci-modes", default="legacy,full,compact")
     args = ap.parse_args()
     global REPS
@@ -426,6 +427,34 @@ def main():
                               "same_bits_as_the_first_mode": bool(torch.equal(x, first[0]) and torch.equal(out["iters"], first[1]) and torch.equal(out["nf"], first[2])),
                               "max_rel_x_diff_vs_fused": float(((x - xf).norm(dim=1) / xf.norm(dim=1)).max()),
                               "slowdown_vs_fused": dt * 1e3 / msf}))
+
+    if "coop" in args.configs:  # ONE problem of n = 2^20 (the reference's callers: one problem of any dim) by reverse communication
+        n, m = 1 << 20, 10
+        i = torch.arange(n, dtype=torch.float64, device=dev)
+        d1 = (1.0 + 99.0 * i / (n - 1)).unsqueeze(0)
+        b1 = torch.sin(i + 1.0).unsqueeze(0)
+
+        def fun(xx):
+            dx = d1 * xx
+            return 0.5 * (dx * xx).sum(1) - (b1 * xx).sum(1), dx - b1
+        for want in ("1", "auto"):
+            if want == "auto":
+                os.environ.pop("FL_COOP_GROUPS", None)
+            else:
+                os.environ["FL_COOP_GROUPS"] = want
+            x = torch.zeros(1, n, dtype=torch.float64, device=dev)
+            NLO.minimize_rci(NLO.LBFGS_, x, fun, Precision=1e-6, MaxIteration=5, Memory=m)  # warm-up
+            x.zero_()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            out = NLO.minimize_rci(NLO.LBFGS_, x, fun, Precision=1e-6, MaxIteration=args.coop_iterations, Memory=m)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t
+            print(json.dumps({"config": f"one L-BFGS problem, n = 2^20, diagonal quadratic kappa 100, reverse communication with a torch objective, "
+                                        f"workgroups per problem: {out['cooperative_groups']}", "ms": dt * 1e3, "steps": out["steps"],
+                              "iterations": int(out["iters"][0]), "iterations_per_s": float(out["iters"][0]) / dt,
+                              "ms_per_step": dt * 1e3 / max(1, out["steps"]), "f": float(out["f"][0]), "gnorm": float(out["gg"][0]) ** 0.5}))
+        os.environ.pop("FL_COOP_GROUPS", None)
 
     if "c5" in args.configs:  # aug-Lagrangian wrapping L-BFGS, batch 8192 n=512, 8 equality constraints
         B, n, M, m = args.c5_batch, 512, 8, 10
