@@ -125,7 +125,17 @@ template <int OBJ, int METHOD> struct BigSolver {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __hip_atomic_fetch_add(coop_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned want = coop_gen * (unsigned)G;
-            while (__hip_atomic_load(coop_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(1);
+            // (bounded: should the workgroups of a problem ever not be resident together -- a GPU shared with another
+            // process -- the wait ends after a few seconds, the handle is flagged and fl_rci_results reports it, instead of
+            // a kernel that never finishes)
+            unsigned spins = 0;
+            while (__hip_atomic_load(coop_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 22)) {
+                    __hip_atomic_store(coop_counter + 1, 0xdeadu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (the flag word)
+                    break;
+                }
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
         __syncthreads();

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(1024) void rci_step_big_kernel(SolveArgs A, int fir
     const int prob = blockIdx.x / groups, group = blockIdx.x - prob * groups, n = A.n;
     S s(A, lds, vec_all, prob);
     if (groups > 1)
-        s.set_cooperative(groups, group, coop_part + (size_t)prob * 2 * groups * Reducer<S::NW>::NVMAX, coop_counter + prob);
+        s.set_cooperative(groups, group, coop_part + (size_t)prob * 2 * groups * Reducer<S::NW>::NVMAX, coop_counter + 2 * prob);
     // cooperative form: the scalars (and the rho ring) are parked in two copies used alternately -- this step reads copy
     // `parity` and its first workgroup writes the other one, so no workgroup can see a half-written block and no barrier
     // is needed between load() and save() (a step that only takes an objective value has none of its own)
@@ -324,7 +324,8 @@ static void launch_rci(Rci *h, const double *f, const double *g, const double *c
 static void launch_rci_big(Rci *h, const double *f, const double *g, int32_t *req)
 {
     const int G = h->coop_groups > 1 ? h->coop_groups : 1;
-    if (G > 1) (void)hipMemsetAsync(h->coop_counter, 0, sizeof(unsigned) * h->batch, h->stream); // this launch's barriers count from 0
+    if (G > 1) // this launch's barriers count from 0 (word 0 of each problem's pair; word 1 is the "gave up waiting" flag: kept)
+        (void)hipMemset2DAsync(h->coop_counter, 2 * sizeof(unsigned), 0, sizeof(unsigned), h->batch, h->stream);
     dim3 grid(h->batch * G), block(1024);
 #define FL_RCI(M)                                                                                                 \
     hipLaunchKernelGGL((rci_step_big_kernel<M>), grid, block, 0, h->stream, h->A, h->first, h->sc, h->vec, h->rho, f, \
@@ -430,15 +431,19 @@ int fl_rci_create(fl_rci **out, int solver, int batch, int n, const fl_options *
         // barriers spin: one 1024-thread workgroup per CU is assumed, 256 CUs) and give each at least two slots.
         // FL_COOP_GROUPS in the environment overrides (tests; 1 switches the cooperative form off).
         using BS = fl::BigSolver<FL_OBJ_EXTERNAL, FL_SOLVER_LBFGS>;
-        int want = 256 / batch;
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+        if (cus > BS::COOP_MAX_GROUPS) cus = BS::COOP_MAX_GROUPS;
+        int want = cus / batch;
         const int nslot = BS::slots_for(n);
         if (want > nslot / 2) want = nslot / 2;
         if (const char *e = std::getenv("FL_COOP_GROUPS")) want = std::atoi(e);
-        if (want > 256 / batch) want = 256 / batch;
+        if (want > cus / batch) want = cus / batch;
         if (want > 1) {
             r.coop_groups = BS::coop_groups(n, want);
             ok = hipMalloc((void **)&r.coop_part, B * 2 * r.coop_groups * fl::Reducer<16>::NVMAX * sizeof(double)) == hipSuccess &&
-                 hipMalloc((void **)&r.coop_counter, B * sizeof(unsigned)) == hipSuccess;
+                 hipMalloc((void **)&r.coop_counter, 2 * B * sizeof(unsigned)) == hipSuccess &&
+                 hipMemsetAsync(r.coop_counter, 0, 2 * B * sizeof(unsigned), r.stream) == hipSuccess;
         }
     }
     if (!ok) {
@@ -639,6 +644,14 @@ int fl_rci_results(fl_rci *h, double *f_dev, double *gg_dev, int32_t *iters_dev,
     const size_t B = (size_t)h->r.batch;
     hipStream_t st = h->r.stream;
     bool ok = true;
+    if (h->r.coop_groups > 1) { // did a cooperative step ever give up waiting for its siblings?  (then nothing can be trusted)
+        std::vector<unsigned> words(2 * B);
+        if (hipMemcpyAsync(words.data(), h->r.coop_counter, 2 * B * sizeof(unsigned), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)
+            return FL_ERR_LAUNCH;
+        for (size_t k = 0; k < B; ++k)
+            if (words[2 * k + 1] != 0) return FL_ERR_LAUNCH;
+    }
     if (f_dev) ok &= hipMemcpyAsync(f_dev, h->r.f_out, B * 8, hipMemcpyDeviceToDevice, st) == hipSuccess;
     if (gg_dev) ok &= hipMemcpyAsync(gg_dev, h->r.gg_out, B * 8, hipMemcpyDeviceToDevice, st) == hipSuccess;
     if (iters_dev) ok &= hipMemcpyAsync(iters_dev, h->r.iters, B * 4, hipMemcpyDeviceToDevice, st) == hipSuccess;
