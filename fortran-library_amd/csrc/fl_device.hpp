@@ -969,6 +969,115 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
         return fast_forward_cs<K, 4>();
     }
 
+    // ---------------------------------------------------------------- the growing loop of StrongWolfe (GROW_K)
+    // "search for larger a" (NO.f90:1499-1515; _fdwithf twin 1620-1634): a <- a * incrmt with f AND f' at every trial until
+    // Armijo fails, f stops falling or the slope turns positive.  The reference walks it in 5 % steps, ~12 of the ~14 trials
+    // of an L-BFGS iteration on the benched quadratics; only the exit depends on the values.  Same idea as fast_forward,
+    // for kernels without constraints: GROW_K consecutive trials per pass share one reduction and skip the pass through
+    // the whole machine; the machine gets the exit trial with the state its own steps would have left (non-exit step:
+    // aold=a; fold=fx; phidold=phidnew; a=aold*incr), x and g are formed again at the exit trial's point.
+    // Measured (gpurun_out/r03_ab_grow_*.txt -> profiles/r03/grow_ab.txt): headline L-BFGS 65 536 x 1024: 163.9 -> 154.9 ms
+    // with two trials per pass (three: 155.3); C2 (Rosenbrock n = 256: a barrier pair per evaluation either way) 2.66 ->
+    // 2.66 ms; the SD / CG kernels have no registers to spare for it (capped at 128 VGPRs: 3-10 would spill; 1 x 16 is at 252).
+#ifndef FL_GROW_K
+#define FL_GROW_K 2
+#endif
+    static constexpr int GROW_K = (!AUG && OBJ != FL_OBJ_EXTERNAL && METHOD == FL_SOLVER_LBFGS && EPT <= 8 && FL_GROW_K > 1) ? FL_GROW_K : 1;
+    static_assert(GROW_K >= 1 && GROW_K <= 3, "3 sums per trial, at most 10 values per reduction");
+    __device__ __forceinline__ bool grow_loop_pending() const { return ls.st == LineSearch::SW_GROW; }
+    template <int K> __device__ __forceinline__ void fast_forward_grow(double &fv_out, double &pv_out)
+    {
+        double aold = ls.aold, fold = ls.fold, pold = ls.phidold;
+        double a_x = ls.a_eval, f_x = 0.0, p_x = 0.0;
+        int consumed = 0;
+        bool found = false;
+        auto next = [&](double a_) { return uni(a_ * ls.incr); }; // a=aold*incrmt: the expression the machine itself forms
+        double as[K];
+        as[0] = ls.a_eval;
+#pragma unroll
+        for (int k = 1; k < K; ++k) as[k] = next(as[k - 1]);
+        for (;;) {
+            double r[3 * K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                double xk[EPT], gk[EPT];
+                if constexpr (X0_LDS) {
+                    load_pad<NW, EPT>(lds + L_X0, xk);
+#pragma unroll
+                    for (int e = 0; e < EPT; ++e) xk[e] = xk[e] + as[k] * p[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < EPT; ++e) xk[e] = x0[X0_LDS ? 0 : e] + as[k] * p[e];
+                }
+                if constexpr (LEAN) obj.init(A, prob, lds + L_XS);
+                obj.eval(xk, gk, r[3 * k], r[3 * k + 1], n, lds + L_XS);
+                r[3 * k + 2] = dot_part<EPT>(gk, p);
+            }
+            R.run(r);
+            double fs[K], ps[K];
+            unsigned exits = 0;
+            double fprev = fold;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                fs[k] = uni(Obj::combine(r[3 * k], r[3 * k + 1]));
+                ps[k] = uni(r[3 * k + 2]);
+                const double bound = ls.fx0 + ls.c1 * as[k] * ls.phid0;
+                exits |= (unsigned)((fs[k] > bound) | (fs[k] >= fprev) | (ps[k] > 0.0)) << k;
+                fprev = fs[k];
+            }
+            exits = __builtin_amdgcn_readfirstlane(exits);
+            if (exits) {
+                const int kx = __builtin_ctz(exits);
+                a_x = as[0];
+                f_x = fs[0];
+                p_x = ps[0];
+#pragma unroll
+                for (int k = 1; k < K; ++k) {
+                    const bool take = kx >= k;
+                    aold = take ? a_x : aold;
+                    fold = take ? f_x : fold;
+                    pold = take ? p_x : pold;
+                    a_x = take ? as[k] : a_x;
+                    f_x = take ? fs[k] : f_x;
+                    p_x = take ? ps[k] : p_x;
+                }
+                consumed += kx;
+                found = true;
+                break;
+            }
+            aold = as[K - 1];
+            fold = fs[K - 1];
+            pold = ps[K - 1];
+            consumed += K;
+            as[0] = next(aold);
+#pragma unroll
+            for (int k = 1; k < K; ++k) as[k] = next(as[k - 1]);
+            if (!(as[0] < 1e300)) { // (a step length running away to infinity: hand the loop back to the machine as it stands)
+                a_x = as[0];
+                break;
+            }
+        }
+        ls.a = ls.a_eval = uni(a_x);
+        ls.aold = uni(aold);
+        ls.fold = uni(fold);
+        ls.phidold = uni(pold);
+        nf += consumed; // (every consumed trial was an f + f' request; the exit trial itself is counted by advance())
+        ng += consumed;
+        // x, g at the exit trial's point (the search may accept it as it is)
+        move(ls.a_eval);
+        double s0, s1;
+        if constexpr (LEAN) obj.init(A, prob, lds + L_XS);
+        obj.eval(x, g, s0, s1, n, lds + L_XS);
+        if (found) {
+            fv_out = f_x;
+            pv_out = p_x;
+        } else { // (ran away: evaluate the pending trial for real)
+            double r3[3] = {s0, s1, dot_part<EPT>(g, p)};
+            R.run(r3);
+            fv_out = uni(Obj::combine(r3[0], r3[1]));
+            pv_out = uni(r3[2]);
+        }
+    }
     // Reverse communication with the CALLER's constraints (AugmentedLagrangian's c, cd callbacks, NO.f90:1928-1934):
     // L = f - lambda.c + miu/2 c.c (L, NO.f90:2198) and, with the caller's gradient already in g,
     // grad L = fd + matmul(cdx, miu*cx - lambda) (Ld, NO.f90:2205; cd_user: [m][n], row j = grad c_j), then g.p, g.g.

@@ -60,6 +60,14 @@ void fl_solve_kernel(SolveArgs A)
                     forwarded = true;
                 }
             }
+            if constexpr (S::GROW_K > 1) { // the growing loop of StrongWolfe (f and f' per trial): GROW_K trials per pass
+                if (full && !(rq & FL_REQ_NOMOVE) && s.grow_loop_pending()) {
+                    s.template fast_forward_grow<S::GROW_K>(fv, pv); // (leaves x, g at the exit trial's point)
+                    have_g = true;
+                    full = false;
+                    forwarded = true;
+                }
+            }
             if (!forwarded && !(rq & FL_REQ_NOMOVE)) s.move(s.request_point());
         } else if (AUG && (rq & FL_REQ_G) && !have_g) { // gradient at the point whose objective is already known
             full = true;
