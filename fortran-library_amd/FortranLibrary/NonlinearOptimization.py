@@ -347,6 +347,8 @@ def minimize_rci(solver, x, fun, options=None, max_steps=10000000, check_every=8
     import torch
     o = options if options is not None else default_options(solver, **kw)
     B, n, out = _prep(x, None, None)
+    if solver == BFGS_ and hess is None:
+        o.exact_step = 0  # no Hessian source: quasi-Newton updates only (the reference would differentiate f' numerically: hess="numerical")
     wants_h = solver == 4 or (solver == BFGS_ and o.exact_step > 0)
     if wants_h and (hess is None or mode != "legacy"):
         raise ValueError("NewtonRaphson / BFGS with ExactStep > 0 by reverse communication: pass hess=callable | 'numerical' (mode 'legacy')")
@@ -433,9 +435,11 @@ def minimize_rci_auglag(solver, x, fun, M, lambda0=None, miu0=1.0, options=None,
     import torch
     o = options if options is not None else default_options(solver, **kw)
     B, n, out = _prep(x, None, None)
+    if solver == BFGS_ and hess is None:
+        o.exact_step = 0  # no Hessian source: quasi-Newton updates only
     wants_h = solver == 4 or (solver == BFGS_ and o.exact_step > 0)
     if wants_h and hess is None:
-        raise ValueError("NewtonRaphson / BFGS with ExactStep > 0 inside: pass hess=callable | 'numerical'")
+        raise ValueError("NewtonRaphson inside: pass hess=callable | 'numerical'")
     lam = torch.zeros(B, M, dtype=torch.float64, device=x.device) if lambda0 is None else \
         lambda0.to(torch.float64).contiguous().clone()
     FL.fl_rci_create_auglag.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double,
