@@ -130,7 +130,7 @@ void linearalgebra_mp_my_dsyev_(const char *jobtype, double *A, double *eigval, 
 // and TrustRegion_basic (NO.f90:1728-1906, 2348-2423; hpp:358-366): solve f'(x) = 0 by minimising |f'(x)|^2.
 // The reference is a wrapper of MKL's closed RCI solver dtrnlsp -- there is no algorithm in the reference to restate
 // (SURVEY.md 8f.4), so this is an own Levenberg-Marquardt iteration with Nielsen's damping update behind the same
-// interface and stopping options: PARITY UNPINNED by construction (same stationary points, different path).
+// interface and stopping options: own path, end points held to the real dtrnlsp's (tests/test_mkl_pins.py).
 // Callbacks on the host; J^T J, J^T f' through fl_dgemm and the damped normal equations through fl_dposv_batched on
 // the GPU.  Bounds (low, up) are honoured by projecting every trial point.
 typedef void (*res_cb)(double *, const double *, const int &, const int &);

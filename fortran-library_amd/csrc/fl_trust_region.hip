@@ -4,8 +4,8 @@
 // The reference is a wrapper of MKL's closed RCI solver dtrnlsp/dtrnlspbc -- there is no algorithm in the reference to
 // restate -- so this is the library's own Levenberg-Marquardt iteration with Nielsen's damping update,
 // the same one the one-problem legacy symbol runs on the host (csrc/fl_linalg.cpp), behind the reference's stopping
-// options (MaxIteration, MaxStepIteration, Precision on ||f'(x)||_2, MinStepLength on ||s||_2): PARITY UNPINNED by
-// construction (same stationary points, own path).  Per step and problem: A = J^T J, g = J^T r on the f64 matrix cores
+// options (MaxIteration, MaxStepIteration, Precision on ||f'(x)||_2, MinStepLength on ||s||_2): own path, END POINTS held to
+// the real MKL dtrnlsp's (tests/golden/mkl_trnlsp.npz, tests/test_mkl_pins.py).  Per step and problem: A = J^T J, g = J^T r on the f64 matrix cores
 // (fl_dgemm_strided), (A + mu I) d = -g by fl_dposv_batched, trial point x + d projected into the box; gain ratio
 // rho = (|r|^2 - |r_new|^2) / (d.(mu d - g)) decides: accept (mu *= max(1/3, 1 - (2 rho - 1)^3), new Jacobian wanted)
 // or reject (mu *= nu, nu *= 2, new trial from the same A, g: they are kept per problem and renewed only by a Jacobian

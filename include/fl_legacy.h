@@ -24,9 +24,10 @@
  * 'NewtonRaphson'; NO.f90:2074-2185); the wrappers L, Ld, L_Ld, Ldd that compose the caller's f, fd, fdd, c, cd, cdd
  * (NO.f90:2193-2240) run on the host next to those callbacks, every inner solve on the GPU.
  * NewtonRaphson and BFGS with ExactStep > 0 call the caller's fdd on the host and ship the Hessian to the GPU
- * (Cholesky solve / inverse there); without fdd the reference calls MKL djacobi (closed, step rule unpublished):
- * here central differences of the caller's fd, h = 1e-8 max(1,|x_j|), 2n gradient calls per Hessian -- same
- * end points, not bit-identical ("parity unpinned" for this branch).
+ * (Cholesky solve / inverse there); without fdd the reference calls MKL djacobi: here fl_djacobi's central differences
+ * of the caller's fd with djacobi's own step rule, 2n gradient calls per Hessian -- the real MKL routine's bits
+ * (tests/golden/mkl_djacobi.npz), so e.g. BFGS with its defaults makes the reference's 844 f / 845 fd callbacks on the
+ * Rosenbrock n = 10 probe.
  */
 #ifndef FL_LEGACY_H
 #define FL_LEGACY_H
@@ -132,8 +133,8 @@ void nonlinearoptimization_mp_lagrangianmultiplier_(fl_fd_cb fd, fl_fdd_cb fdd, 
 
 /* TrustRegion / TrustRegion_basic (NO.f90:1728-1906, 2348-2423; hpp:358-366): f'(x) = 0 by minimising |f'(x)|^2.
  * The reference wraps MKL's closed dtrnlsp solver; here an own Levenberg-Marquardt iteration sits behind the same
- * interface (callbacks on the host, J^T J / damped normal equations on the GPU): same stationary points, parity
- * unpinned by construction.  subroutine fd(f'(x),x,M,N); integer function Jacobian(J(x),x,M,N), J is M x N. */
+ * interface (callbacks on the host, J^T J / damped normal equations on the GPU): same stationary points -- own path,
+ * end points held to the real dtrnlsp's (tests/golden/mkl_trnlsp.npz).  subroutine fd(f'(x),x,M,N); integer function Jacobian(J(x),x,M,N), J is M x N. */
 typedef void (*fl_residue_cb)(double *fdx, const double *x, const int *M, const int *N);
 typedef int (*fl_jacobian_cb)(double *Jx, const double *x, const int *M, const int *N);
 void __nonlinearoptimization_MOD_trustregion_basic(fl_residue_cb fd, fl_jacobian_cb Jacobian, double *x, const int *M,

@@ -360,7 +360,7 @@ int fl_djacobi(void (*fcn)(const int *m, const int *n, const double *x, double *
 /* ---- TrustRegion (NO.f90:1728-1906) for a batch, on the device, by reverse communication ------------------------
  * Solves f'(x) = 0 in the least-squares sense (M equations, N unknowns, M >= N; optional box low <= x <= up shared by
  * the batch) for `batch` independent problems.  The reference wraps MKL's closed dtrnlsp solver; this is the library's
- * own Levenberg-Marquardt iteration (parity unpinned by construction) behind the reference's stopping options
+ * own Levenberg-Marquardt iteration (own path; end points held to the real dtrnlsp's) behind the reference's stopping options
  * (MaxIteration, MaxStepIteration, Precision on ||f'(x)||_2, MinStepLength on the step).  Ask / tell:
  *   fl_trust_region_step(h, x_dev, r_dev, J_dev, request_dev): first call x_dev [batch][N] = starting points (r_dev,
  *   J_dev may be NULL); afterwards r_dev [batch][M] = f'(x) and J_dev [batch][N][M] = the M x N Jacobian, column-major
