@@ -367,7 +367,10 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
     using G = Geo<NW, EPT>;
     using Obj = Objective<OBJ, NW, EPT>;
     static constexpr int NPAD = G::NPAD;
-    static constexpr int BF_UNROLL = 4;
+#ifndef FL_BF_UNROLL
+#define FL_BF_UNROLL 4
+#endif
+    static constexpr int BF_UNROLL = FL_BF_UNROLL; // columns of H in flight per thread in the streaming passes
     static constexpr bool NEEDS_G0 = (METHOD != FL_SOLVER_SD && METHOD != FL_SOLVER_NEWTON);
     // LDS carve (doubles)
     static constexpr int L_RED = 0;                              // [2][NVMAX][NW]
