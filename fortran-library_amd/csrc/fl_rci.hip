@@ -64,6 +64,9 @@ __global__ __launch_bounds__(NW * 64) void rci_step_kernel(SolveArgs A, int firs
     double fv = 0.0, pv = 0.0;
     if (first) {
         rq = s.start();
+        s.ls_begun = true; // (the parked rows p, x0 start defined: zero direction, the initial guess)
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) s.x0[k] = s.x[k];
     } else {
         s.load(sc, vec, rho, fv, pv);
         double ggv = s.gg;
