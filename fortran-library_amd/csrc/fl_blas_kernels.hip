@@ -12,7 +12,12 @@
 // column index to the M side: accumulator register r of lane l is then C(m = base + (l & 15), n = base + (l >> 4) + 4 r)
 // and the 16 lanes of a row write 128 contiguous bytes of the column-major C.
 //
-// DSYEV: cyclic two-sided Jacobi with the round-robin (tournament) ordering: a step applies n/2 disjoint rotations at
+// DSYEV, three routes (the legacy symbol My_dsyev chooses, csrc/fl_linalg.cpp):
+//   'N': Householder tridiagonalisation, one launch per reflector (tridiag_step_kernel), + multisection (fl_dsyev_values);
+//   'V': the same tridiagonalisation with the reflectors kept, inverse iteration, Cholesky-QR / Newton-Schulz on the
+//        matrix cores, back-transformation (csrc/fl_eig_vectors.hip: fl_dsyev_vectors), checked on the device;
+//   the fallback of 'V' when that check fails, and beyond n = 6144: cyclic two-sided Jacobi (fl_dsyev_jacobi), below.
+// Jacobi: cyclic two-sided with the round-robin (tournament) ordering: a step applies n/2 disjoint rotations at
 // once, A <- J^T (A J), V <- V J; a sweep is n - 1 steps.  ONE launch per step (jacobi_step_kernel): the workgroup of a
 // pair stages its two columns in LDS, applies the previous step's pending row rotations to them, forms its own rotation
 // from the finished 2x2 block and writes the rotated columns (and V's) in place; jacobi_rows applies the last pending
@@ -355,33 +360,83 @@ __device__ __forceinline__ double wg256_sum(double v, double *scratch)
 }
 __global__ __launch_bounds__(256) void tridiag_step_kernel(int n, int k, double *A, int ld, const double *vprev,
                                                            const double *pprev, const double *tauprev, double *vnext,
-                                                           double *pnext, double *taunext, double *dvec, double *evec)
+                                                           double *pnext, double *taunext, double *dvec, double *evec,
+                                                           double *tauvec, double *Vkeep, int ldk)
 {
     extern __shared__ double tl[];
     double *w = tl, *vv = tl + n, *vn = tl + 2 * n, *scr = tl + 3 * n;
     const int tid = threadIdx.x, mp = n - k; // mp = length of the previous step's vectors (rows k .. n-1)
     const bool first = (k == 0);
+    const double *colk = A + (size_t)k * ld;
+    const int m = n - k - 1; // rows / columns of the trailing matrix T_k
+    const int lane = tid & 63, gw = blockIdx.x * 4 + (tid >> 6), nwv = gridDim.x * 4;
+    // 0. Everything this workgroup reads first -- its share of v_{k-1}, p_{k-1}, of column k and the first rows of its
+    //    first trailing column -- is requested NOW, before anything waits: the step is a chain of dependent O(m) phases
+    //    and one memory round trip instead of four is most of what a step costs (n = 1024: 7.5 -> see DESIGN.md 8).
+    //    (Unconditional loads at clamped indices, used under the guards below: a load the compiler can make conditional
+    //    turns the waits after it into vmcnt(0).)
+    constexpr int PF = 4, PFA = 8;
+    double pf_v[PF], pf_p[PF], pf_c[PF], pf_a[PFA];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+        const int r = tid + 256 * j;
+        pf_v[j] = vprev[r < mp ? r : mp - 1];
+        pf_p[j] = pprev[r < mp ? r : mp - 1];
+        pf_c[j] = colk[k + 1 + (r < m ? r : m - 1)];
+    }
+    {
+        const double *col0 = A + (size_t)(k + 1 + (gw < m ? gw : m - 1)) * ld + (k + 1);
+#pragma unroll
+        for (int j = 0; j < PFA; ++j) pf_a[j] = col0[lane + 64 * j < m ? lane + 64 * j : m - 1];
+    }
     // 1. w_{k-1} = p + alpha v, alpha = -tau/2 (p.v)   (dsytd2)
     double w0 = 0.0, v0 = 0.0;
     if (!first) {
         double s = 0.0;
-        for (int r = tid; r < mp; r += 256) {
-            const double vr = vprev[r];
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const int r = tid + 256 * j;
+            if (r < mp) {
+                vv[r] = pf_v[j];
+                w[r] = pf_p[j]; // (p for now)
+                s += pf_p[j] * pf_v[j];
+            }
+        }
+        for (int r = tid + 256 * PF; r < mp; r += 256) {
+            const double vr = vprev[r], pr = pprev[r];
             vv[r] = vr;
-            s += pprev[r] * vr;
+            w[r] = pr;
+            s += pr * vr;
         }
         s = wg256_sum(s, scr);
         const double alpha = -0.5 * tauprev[0] * s;
-        for (int r = tid; r < mp; r += 256) w[r] = pprev[r] + alpha * vv[r];
+        for (int r = tid; r < mp; r += 256) w[r] = w[r] + alpha * vv[r];
         __syncthreads();
         w0 = w[0];
         v0 = vv[0];
+        // with eigenvectors wanted: reflector k-1 is kept in column k-1 of Vkeep (ldk >= n, zero-initialised by the caller:
+        // rows above the reflector and the padding below row n read as zero, so whoever applies it needs no mask), as
+        // u = sqrt(tau) v (tau is 0 or in [1, 2]): H = I - u u^T needs no second array
+        if (tauvec && blockIdx.x == 0) {
+            double *keep = Vkeep + (size_t)(k - 1) * ldk + k;
+            const double st = sqrt(tauprev[0]);
+            for (int r = tid; r < mp; r += 256) keep[r] = st * vv[r];
+            if (tid == 0) tauvec[k - 1] = tauprev[0];
+        }
     }
     // 2. column k after the update: d_k on the diagonal, x_k = rows k+1 .. n-1 below it -> reflector (dlarfg)
-    const double *colk = A + (size_t)k * ld;
-    const int m = n - k - 1; // rows / columns of the trailing matrix T_k
     double nrm2 = 0.0;
-    for (int r = tid; r < m; r += 256) {
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+        const int r = tid + 256 * j;
+        if (r < m) {
+            double x = pf_c[j];
+            if (!first) x = x - (vv[r + 1] * w0 + w[r + 1] * v0);
+            vn[r] = x;
+            if (r > 0) nrm2 += x * x;
+        }
+    }
+    for (int r = tid + 256 * PF; r < m; r += 256) {
         double x = colk[k + 1 + r];
         if (!first) x = x - (vv[r + 1] * w0 + w[r + 1] * v0);
         vn[r] = x;
@@ -410,12 +465,27 @@ __global__ __launch_bounds__(256) void tridiag_step_kernel(int n, int k, double 
         }
     }
     // 3. the trailing columns: update of step k-1, stored, and their share of p_k = tau_k T_k v_k
-    const int lane = tid & 63, gw = blockIdx.x * 4 + (tid >> 6), nwv = gridDim.x * 4;
     for (int c = gw; c < m; c += nwv) {
         double *col = A + (size_t)(k + 1 + c) * ld + (k + 1);
         const double wj = first ? 0.0 : w[c + 1], vj = first ? 0.0 : vv[c + 1];
         double acc = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
         int r = lane;
+        if (c == gw) { // the rows requested at the top of the kernel
+#pragma unroll
+            for (int j = 0; j < PFA; ++j) {
+                const int rr = lane + 64 * j;
+                if (rr < m) {
+                    double a = pf_a[j];
+                    if (!first) {
+                        a = a - (vv[rr + 1] * wj + w[rr + 1] * vj);
+                        col[rr] = a;
+                    }
+                    if (j & 1) acc1 += a * vn[rr];
+                    else acc += a * vn[rr];
+                }
+            }
+            r = lane + 64 * PFA;
+        }
         for (; r + 192 < m; r += 256) { // four independent rows in flight per lane
             double a0 = col[r], a1 = col[r + 64], a2 = col[r + 128], a3 = col[r + 192];
             if (!first) {
@@ -633,18 +703,14 @@ int fl_dsyev_jacobi(char jobz, int n, double *A_dev, int lda, double *w_dev, voi
 }
 
 
-// Eigenvalues only (jobz = 'N'): Householder tridiagonalisation in n - 1 launches, then multisection.  A_dev (n x n,
-// lda = n, lower triangle referenced) is destroyed; w_dev: the eigenvalues in ascending order.  n <= 6144 (three
-// vectors of the step live in LDS); workspace as for fl_dsyev_jacobi.
-int fl_dsyev_values(int n, double *A_dev, int lda, double *w_dev, void *workspace_dev, size_t workspace_bytes, void *stream)
+// Householder tridiagonalisation in n - 1 launches, then the tridiagonal's eigenvalues by multisection: the shared front of
+// fl_dsyev_values and fl_dsyev_vectors (fl_eig_vectors.hip).  ws: (6 n + 4) doubles; on return d = ws + 4 n + 4 (n - 1
+// entries; the last diagonal entry stays at A(n-1, n-1)), e = d + n.  tauvec (n doubles) non-NULL: reflector k is kept in
+// rows k+1 .. n-1 of column k of Vkeep (ldk >= n, zeroed by the caller) as u_k = sqrt(tau_k) v_k (H_k = I - u_k u_k^T),
+// tau_k in tauvec[k], k < n - 2.
+int fl_sytrd_values(int n, double *A_dev, double *w_dev, double *ws, double *tauvec, double *Vkeep, int ldk, void *stream)
 {
-    if (!A_dev || !w_dev || n <= 0 || lda != n) return FL_ERR_INVALID_ARGUMENT;
-    if (n > 6144) return FL_ERR_UNSUPPORTED_SIZE;
-    if (!workspace_dev || workspace_bytes < fl_dsyev_workspace_bytes(n)) return FL_ERR_WORKSPACE;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FL_ERR_NO_DEVICE;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    double *ws = static_cast<double *>(workspace_dev);
     double *vbuf = ws, *pbuf = ws + 2 * (size_t)n, *tau = ws + 4 * (size_t)n, *dvec = tau + 4, *evec = dvec + n;
     const size_t lds_step = ((size_t)3 * n + 16) * sizeof(double), lds_sturm = (size_t)2 * n * sizeof(double);
     if (lds_step > 48 * 1024 &&
@@ -662,12 +728,24 @@ int fl_dsyev_values(int n, double *A_dev, int lda, double *w_dev, void *workspac
         wgs = wgs < 1 ? 1 : (wgs > 512 ? 512 : wgs);
         hipLaunchKernelGGL(fl::tridiag_step_kernel, dim3(wgs), dim3(256), lds_step, st, n, k, A_dev, n, vbuf + (size_t)prv * n,
                            pbuf + (size_t)prv * n, tau + prv, vbuf + (size_t)cur * n, pbuf + (size_t)cur * n, tau + cur, dvec,
-                           evec);
+                           evec, tauvec, Vkeep, ldk);
     }
     // the last diagonal entry took its final update in the last step's column pass (n = 1: the matrix itself)
     hipLaunchKernelGGL(fl::sturm_multisection_kernel, dim3((n + 3) / 4), dim3(256), lds_sturm, st, n, dvec, evec,
                        A_dev + (size_t)(n - 1) * n + (n - 1), w_dev);
     return fl::launch_status();
+}
+
+// Eigenvalues only (jobz = 'N'): A_dev (n x n, lda = n, lower triangle referenced) is destroyed; w_dev: the eigenvalues
+// in ascending order.  n <= 6144 (three vectors of the step live in LDS); workspace as for fl_dsyev_jacobi.
+int fl_dsyev_values(int n, double *A_dev, int lda, double *w_dev, void *workspace_dev, size_t workspace_bytes, void *stream)
+{
+    if (!A_dev || !w_dev || n <= 0 || lda != n) return FL_ERR_INVALID_ARGUMENT;
+    if (n > 6144) return FL_ERR_UNSUPPORTED_SIZE;
+    if (!workspace_dev || workspace_bytes < fl_dsyev_workspace_bytes(n)) return FL_ERR_WORKSPACE;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FL_ERR_NO_DEVICE;
+    return fl_sytrd_values(n, A_dev, w_dev, static_cast<double *>(workspace_dev), nullptr, nullptr, 0, stream);
 }
 
 } // extern "C"

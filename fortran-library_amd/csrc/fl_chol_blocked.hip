@@ -66,11 +66,13 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(int n, int k0, double *A
         __syncthreads();
         if (tid < CNB && tid >= j) S[j][tid] = (tid == j) ? ajj : S[j][tid] / ajj;
         __syncthreads();
-        // trailing columns c > j of the block: S[c][r] -= L[r][j] L[c][j], r >= c (only the (nb-j-1)^2 square is visited)
-        const int mrest = nb - j - 1;
-        for (int e = tid; e < mrest * mrest; e += 256) {
-            const int c = j + 1 + e / mrest, r = j + 1 + e % mrest;
-            if (r >= c) S[c][r] = S[c][r] - S[j][r] * S[j][c];
+        // trailing columns c > j of the block: S[c][r] -= L[r][j] L[c][j], r >= c (a thread keeps its row, four columns
+        // per pass: no index arithmetic in the loop)
+        {
+            const int r = tid & (CNB - 1);
+            const double lrj = S[j][r];
+            for (int c = j + 1 + (tid >> 6); c < nb; c += 4)
+                if (r >= c) S[c][r] = S[c][r] - lrj * S[j][c];
         }
         __syncthreads();
     }
@@ -93,11 +95,11 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(int n, int k0, double *A
     }
     __syncthreads();
     __shared__ double Tm[CNB][CNB / 2 + 1]; // T = B A^-1 of every pair of the level: Tm[row of B][column within the pair]
-    for (int sz = 1; sz < CNB; sz *= 2) {
+    for (int sz = 1, lg = 0; sz < CNB; sz *= 2, ++lg) {
         // pair p covers rows/cols [2 p sz, 2 p sz + 2 sz): A = first half, C = second half, B = L(second, first)
         const int npairs = CNB / (2 * sz), per = sz * sz;
         for (int e = tid; e < npairs * per; e += 256) {
-            const int pr = e / per, q = e - pr * per, rr = q / sz, cc = q - rr * sz;
+            const int pr = e >> (2 * lg), q = e & (per - 1), rr = q >> lg, cc = q & (sz - 1);
             const int a0 = 2 * pr * sz, c0 = a0 + sz;
             double t = 0.0;
             for (int k = cc; k < sz; ++k) t += S[a0 + k][c0 + rr] * Wt[a0 + cc][a0 + k]; // B(rr,k) * Ainv(k,cc)
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(int n, int k0, double *A
         }
         __syncthreads();
         for (int e = tid; e < npairs * per; e += 256) {
-            const int pr = e / per, q = e - pr * per, rr = q / sz, cc = q - rr * sz;
+            const int pr = e >> (2 * lg), q = e & (per - 1), rr = q >> lg, cc = q & (sz - 1);
             const int a0 = 2 * pr * sz, c0 = a0 + sz;
             double t = 0.0;
             for (int k = 0; k <= rr; ++k) t += Wt[c0 + k][c0 + rr] * Tm[c0 + k][cc]; // Cinv(rr,k) * T(k,cc)
@@ -307,6 +309,23 @@ int fl_dpotri_blocked(int batch, int n, double *A_dev, int lda, double *X_dev, i
     rc = fl_dgemm_strided(1, 0, n, n, n, 1.0, X_dev, n, (size_t)n * n, X_dev, n, (size_t)n * n, 0.0, A_dev, lda, (size_t)n * lda,
                           batch, 0, st);
     return rc;
+}
+
+// Whitening by a Gram matrix (the Cholesky-QR step of fl_dsyev_vectors): G (n x n, ldg, lower referenced, SPD) -> its
+// Cholesky factor L; Y (n x ncols, ld n) <- L^{-1} Y, so that the ROWS of Y become orthonormal when G = Y Y^T.
+// *info_dev != 0: G was not positive definite to rounding (Y is then not to be used).  ws: fl_chol_blocked_workspace_bytes(1, n, ncols).
+int fl_chol_whiten(int n, int ncols, double *G_dev, int ldg, double *Y_dev, int32_t *info_dev, void *ws_dev, size_t ws_bytes,
+                   void *stream)
+{
+    if (!G_dev || !Y_dev || !info_dev || n <= 0 || ncols <= 0 || ldg < n) return FL_ERR_INVALID_ARGUMENT;
+    if (!ws_dev || ws_bytes < fl_chol_blocked_workspace_bytes(1, n, ncols)) return FL_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    fl::Chol c;
+    int rc = setup(c, 1, n, G_dev, ldg, (size_t)n * ldg, info_dev, static_cast<double *>(ws_dev), st);
+    if (rc != FL_OK) return rc;
+    double *tmp = c.P + c.strideP; // [CNB][ncols]
+    if ((rc = fl::potrf(c)) != FL_OK) return rc;
+    return fl::forward(c, Y_dev, ncols, (size_t)n * ncols, tmp, (size_t)fl::CNB * ncols);
 }
 
 } // extern "C"

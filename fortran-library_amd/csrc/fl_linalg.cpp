@@ -6,9 +6,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <numeric>
 #include <vector>
 
@@ -81,18 +83,56 @@ void __linearalgebra_MOD_my_dsyev(const char *jobtype, double *A, double *eigval
         std::fprintf(stderr, "FortranLibrary(MI355X) My_dsyev: no HIP device; A is unchanged\n");
         return;
     }
-    const size_t a = sizeof(double) * (size_t)n * n, wsb = fl_dsyev_workspace_bytes(n);
-    DeviceBuffer Ad(a), Wd(sizeof(double) * n), ws(wsb);
     const bool vec = jobtype && (*jobtype == 'V' || *jobtype == 'v');
+    const size_t a = sizeof(double) * (size_t)n * n;
+    // with eigenvectors: tridiagonalisation + inverse iteration + Cholesky-QR + back-transformation (fl_dsyev_vectors),
+    // whose result is checked on the device; cyclic Jacobi if that check fails (or beyond its size, or on request:
+    // FL_DSYEV_JACOBI=1 in the environment)
+    const char *force = std::getenv("FL_DSYEV_JACOBI");
+    bool fast_vec = vec && n <= 6144 && !(force && force[0] == '1');
+    const size_t wsb = std::max(fl_dsyev_workspace_bytes(n), fast_vec ? fl_dsyev_vectors_workspace_bytes(n) : (size_t)0);
+    const char *dbg = std::getenv("FL_DSYEV_DEBUG");
+    const bool debug = dbg && dbg[0] == '1';
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+    DeviceBuffer Ad(a), Wd(sizeof(double) * n), ws(wsb);
+    const double t_alloc = now();
     int sweeps = 0;
-    bool ok = Ad.p && Wd.p && ws.p && hipMemcpy(Ad.p, A, a, hipMemcpyHostToDevice) == hipSuccess;
-    // eigenvalues only: tridiagonalisation + multisection (ascending already); with vectors, or beyond its size: Jacobi
+    // dsyev scales a matrix whose norm is close to the under/overflow thresholds before it squares anything (dlascl);
+    // here: by a power of two (exact) to max |a_ij| ~ 1 when that maximum is outside [1e-100, 1e100]
+    double amax = 0.0, scale = 1.0;
+    for (int j = 0; j < n; ++j)
+        for (int i = j; i < n; ++i) amax = std::max(amax, std::fabs(A[(size_t)j * n + i])); // 'L': the lower triangle
+    std::vector<double> scaled;
+    const double *src = A;
+    if (std::isfinite(amax) && amax > 0.0 && (amax < 1e-100 || amax > 1e100)) {
+        scale = std::scalbn(1.0, -std::ilogb(amax));
+        scaled.resize((size_t)n * n);
+        for (size_t k = 0; k < (size_t)n * n; ++k) scaled[k] = A[k] * scale;
+        src = scaled.data();
+    }
+    bool ok = Ad.p && Wd.p && ws.p && hipMemcpy(Ad.p, src, a, hipMemcpyHostToDevice) == hipSuccess;
+    bool vectors_in_A = false;
+    const double t_up = now();
+    if (ok && fast_vec) {
+        const int rc = fl_dsyev_vectors(n, Ad.as<double>(), n, Wd.as<double>(), ws.p, wsb, nullptr, nullptr);
+        if (rc == FL_OK) vectors_in_A = true;
+        else if (rc == 1) { // the basis did not pass its check: Jacobi on a fresh copy
+            fast_vec = false;
+            ok = hipMemcpy(Ad.p, src, a, hipMemcpyHostToDevice) == hipSuccess;
+        } else ok = false;
+    }
+    // eigenvalues only: tridiagonalisation + multisection (ascending already); beyond its size: Jacobi
     const bool values_only = !vec && n <= 6144;
-    if (values_only) ok = ok && fl_dsyev_values(n, Ad.as<double>(), n, Wd.as<double>(), ws.p, wsb, nullptr) == FL_OK;
+    if (vectors_in_A) {
+    } else if (values_only) ok = ok && fl_dsyev_values(n, Ad.as<double>(), n, Wd.as<double>(), ws.p, wsb, nullptr) == FL_OK;
     else ok = ok && fl_dsyev_jacobi(vec ? 'V' : 'N', n, Ad.as<double>(), n, Wd.as<double>(), ws.p, wsb, 60, &sweeps, nullptr) == FL_OK;
+    const double t_solved = now();
     std::vector<double> w(n), V;
     ok = ok && hipMemcpy(w.data(), Wd.p, sizeof(double) * n, hipMemcpyDeviceToHost) == hipSuccess;
-    if (ok && vec) {
+    if (ok && vectors_in_A) // ascending already, the vectors in place: straight into the caller's array
+        ok = hipMemcpy(A, Ad.p, a, hipMemcpyDeviceToHost) == hipSuccess;
+    else if (ok && vec) {
         V.resize((size_t)n * n);
         ok = hipMemcpy(V.data(), ws.as<double>() + (size_t)n * n, a, hipMemcpyDeviceToHost) == hipSuccess;
     }
@@ -101,12 +141,15 @@ void __linearalgebra_MOD_my_dsyev(const char *jobtype, double *A, double *eigval
         return;
     }
     if (sweeps < 0) std::fprintf(stderr, "FortranLibrary(MI355X) My_dsyev: Jacobi sweeps exhausted before convergence\n");
+    if (debug)
+        std::fprintf(stderr, "My_dsyev n=%d: alloc %.2f ms, scan + upload %.2f ms, device %.2f ms, download %.2f ms\n", n, t_alloc - t_begin,
+                     t_up - t_alloc, t_solved - t_up, now() - t_solved);
     // eigenvalues in ascending order, eigenvectors follow (dsyev's contract, LinearAlgebra.f90:877)
     std::vector<int> order(n);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return w[x] < w[y]; });
-    for (int k = 0; k < n; ++k) eigval[k] = w[order[k]];
-    if (vec)
+    for (int k = 0; k < n; ++k) eigval[k] = w[order[k]] / scale;
+    if (vec && !vectors_in_A)
         for (int k = 0; k < n; ++k) std::copy(V.begin() + (size_t)order[k] * n, V.begin() + (size_t)(order[k] + 1) * n, A + (size_t)k * n);
 }
 // the ifort manglings (FortranLibrary.hpp:27-43)

@@ -156,8 +156,12 @@ void nonlinearoptimization_mp_trustregion_(fl_residue_cb fd, double *x, const in
                                            const double *Precision, const double *MinStepLength);
 
 /* LinearAlgebra entry points the reference's C++ header binds (cpp/FortranLibrary.hpp:48-63; LinearAlgebra.f90:182-196,
- * 879-887).  Host arrays, column-major; handed to rocBLAS dgemm / rocSOLVER dsyev on the GPU (the reference hands
- * them to MKL): same results to rounding, eigenvectors up to sign. */
+ * 879-887).  Host arrays, column-major; computed by this library's own kernels on the GPU (the reference hands them to
+ * MKL): fl_dgemm on the f64 matrix cores; My_dsyev 'N' by tridiagonalisation + multisection (fl_dsyev_values), 'V' by
+ * tridiagonalisation + inverse iteration + Cholesky-QR + back-transformation (fl_dsyev_vectors; the basis is checked on
+ * the device, cyclic Jacobi if the check fails; FL_DSYEV_JACOBI=1 in the environment forces Jacobi).  Like dsyev the
+ * matrix is rescaled first when max |a_ij| is outside [1e-100, 1e100].  Same results to rounding, eigenvectors up to
+ * sign (and up to a rotation inside numerically multiple eigenvalues). */
 void __linearalgebra_MOD_my_dgemm(const double *A, const double *B, double *C, const int *M, const int *K, const int *N);
 void __linearalgebra_MOD_my_dgemm_t(const double *A, const double *B, double *C, const int *M, const int *K, const int *N);
 void __linearalgebra_MOD_my_dsyev(const char *jobtype, double *A, double *eigval, const int *N, int len_jobtype);

@@ -207,6 +207,17 @@ int fl_dsyev_jacobi(char jobz, int n, double *A_dev, int lda, double *w_dev, voi
  * tridiagonalisation, one launch per reflector, then the tridiagonal's eigenvalues by multisection with Sturm counts;
  * w_dev ascending, A_dev destroyed, n <= 6144, workspace fl_dsyev_workspace_bytes(n). */
 int fl_dsyev_values(int n, double *A_dev, int lda, double *w_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
+/* jobz = 'V' for one large matrix (My_dsyev('V',...), LinearAlgebra.f90:879-887; csrc/fl_eig_vectors.hip): the same
+ * tridiagonalisation with the reflectors kept, the tridiagonal's eigenvectors by inverse iteration (one lane per
+ * vector), made orthonormal all at once by Cholesky-QR on the f64 matrix cores, back-transformed with one eigenvector
+ * per wave.  A_dev (lda = n, lower triangle referenced) <- the normalised eigenvectors (columns), w_dev ascending;
+ * n <= 6144.  The basis is checked on the device (orthogonality and tridiagonal residuals to 512 eps) before it is
+ * returned: FL_OK, or 1 = the check failed, A_dev / w_dev undefined -- run fl_dsyev_jacobi on a fresh copy, as the legacy
+ * symbol does.  quality_host (may be NULL): max |Y Y^T - I|, max |T y - lambda y| / ||T||, Cholesky-QR passes.
+ * Synchronises the stream. */
+size_t fl_dsyev_vectors_workspace_bytes(int n);
+int fl_dsyev_vectors(int n, double *A_dev, int lda, double *w_dev, void *workspace_dev, size_t workspace_bytes,
+                     double *quality_host, void *stream);
 
 /* The BFGS inverse-Hessian update AS THE REFERENCE WRITES IT: U = I - rho y s^T, rho = 1/(y.s),
  * H <- matmul(transpose(U), matmul(H, U)) + rho s s^T  (NO.f90:958-962; LinearAlgebra.f90:105-114

@@ -230,6 +230,102 @@ def test_my_dsyev_values_only_edge_cases(n):
         assert np.abs(w - ref).max() <= 4 * max(n, 4) * 2.3e-16 * norm + 1e-300, (name, np.abs(w - ref).max(), norm)
 
 
+def _eig_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    G = rng.standard_normal((n, n))
+    Q, _ = np.linalg.qr(G)
+    rep = np.repeat(np.arange(1, n // 8 + 2), 8)[:n].astype(float)
+    off = np.ones(max(n - 1, 0))
+    cases = {
+        "random": 0.5 * (G + G.T),
+        "identity": np.eye(n),
+        "diagonal": np.diag(np.arange(n, 0, -1.0)),
+        "tridiagonal": np.diag(np.full(n, 2.0)) - np.diag(off, 1) - np.diag(off, -1),
+        "projector": Q[:, : max(1, n // 3)] @ Q[:, : max(1, n // 3)].T,
+        "graded": (Q * np.logspace(0, -12, n)[None, :]) @ Q.T,
+        "zero": np.zeros((n, n)),
+        "wilkinson": np.diag(np.abs(np.arange(n) - n // 2).astype(float)) + np.diag(off, 1) + np.diag(off, -1),
+        "clusters": (Q * rep[None, :]) @ Q.T,                                                 # eigenvalues of multiplicity 8
+        "near_clusters": (Q * (rep + 1e-13 * rng.standard_normal(n))[None, :]) @ Q.T,        # ... split at the 1e-13 level
+        "tiny": 1e-200 * 0.5 * (G + G.T),                                                     # squares underflow / overflow
+        "huge": 1e+200 * 0.5 * (G + G.T),
+    }
+    return {k: 0.5 * (v + v.T) for k, v in cases.items()}
+
+
+def _check_basis(name, A, S, w, n):
+    norm = max(np.abs(A).sum(axis=1).max(), 1e-300)
+    An, wn = A / norm, w / norm  # (the extreme scalings would overflow in the products below)
+    ref = np.linalg.eigvalsh(An)
+    assert np.all(np.diff(w) >= 0), name
+    assert np.abs(wn - ref).max() <= 4 * max(n, 4) * 2.3e-16, (name, np.abs(wn - ref).max())
+    # the bar of the library's own device-side check (512 eps on the tridiagonal's vectors) plus the two orthogonal
+    # transformations around it; typical figures are ~1e-16 (residual) and ~2e-15 (orthogonality), see DESIGN.md 8
+    bar = max(600, 4 * n) * 2.3e-16
+    assert np.abs(An @ S - S * wn[None, :]).max() <= bar, (name, np.abs(An @ S - S * wn[None, :]).max())
+    assert np.abs(S.T @ S - np.eye(n)).max() <= bar, (name, np.abs(S.T @ S - np.eye(n)).max())
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 65, 130, 513])
+def test_my_dsyev_with_vectors_edge_cases(n):
+    """jobz = 'V' runs tridiagonalisation + inverse iteration + Cholesky-QR + back-transformation (fl_dsyev_vectors):
+    multiple and nearly multiple eigenvalues (identity, a projector, clusters of 8, Wilkinson's pairs), matrices that are
+    already tridiagonal / diagonal, graded and extremely scaled entries.  Residuals and orthogonality to n eps."""
+    FL = _fl()
+    for name, A in _eig_cases(n, 300 + n).items():
+        S = np.asfortranarray(np.tril(A))
+        w = np.full(n, np.nan)
+        FL.__linearalgebra_MOD_my_dsyev(b"V", S.ctypes.data_as(dp), w.ctypes.data_as(dp), C.byref(C.c_int(n)), C.c_int(1))
+        _check_basis(name, A, S, w, n)
+
+
+@pytest.mark.parametrize("n", [5, 64, 200, 1024, 1100, 2500])
+def test_fl_dsyev_vectors_passes_its_own_check_and_reports_it(n):
+    """the device entry itself: FL_OK (not the Jacobi fallback) on every case but the extreme scalings, which the legacy
+    symbol rescales first (dsyev's dlascl) and the device entry reports as 1 = 'check failed'; its quality figures are
+    those of the basis it returns"""
+    FL = _fl()
+    FL.fl_dsyev_vectors_workspace_bytes.restype = C.c_size_t
+    dev = torch.device("cuda:0")
+    wsb = FL.fl_dsyev_vectors_workspace_bytes(n)
+    ws = torch.empty((wsb + 7) // 8, dtype=torch.float64, device=dev)
+    names = ("random", "projector", "near_clusters", "tiny") if n > 1024 else None
+    for name, A in _eig_cases(n, 500 + n).items():
+        if names and name not in names:
+            continue
+        Ad = torch.tensor(np.tril(A).T.copy(), device=dev)  # column-major, lower triangle only
+        w = torch.zeros(n, dtype=torch.float64, device=dev)
+        q = (C.c_double * 3)()
+        rc = FL.fl_dsyev_vectors(C.c_int(n), C.c_void_p(Ad.data_ptr()), C.c_int(n), C.c_void_p(w.data_ptr()),
+                                 C.c_void_p(ws.data_ptr()), C.c_size_t(wsb), q, None)
+        torch.cuda.synchronize()
+        if name in ("tiny", "huge"):
+            assert rc in (0, 1), (name, rc)
+            continue
+        assert rc == 0, (name, rc, list(q))
+        assert q[0] <= 512 * 2.3e-16 and q[1] <= 512 * 2.3e-16 and q[2] in (1.0, 2.0, 3.0), (name, list(q))
+        _check_basis(name, A, Ad.cpu().numpy().T, w.cpu().numpy(), n)
+    # argument checks
+    assert FL.fl_dsyev_vectors(C.c_int(n), None, C.c_int(n), C.c_void_p(ws.data_ptr()), C.c_void_p(ws.data_ptr()), C.c_size_t(wsb), None, None) == -1
+    assert FL.fl_dsyev_vectors(C.c_int(n), C.c_void_p(ws.data_ptr()), C.c_int(n), C.c_void_p(ws.data_ptr()), C.c_void_p(ws.data_ptr()),
+                               C.c_size_t(8), None, None) == -3
+
+
+def test_my_dsyev_jacobi_on_request(monkeypatch):
+    """FL_DSYEV_JACOBI=1: the cyclic Jacobi path (the fallback of the 'V' job) stays reachable and correct"""
+    FL = _fl()
+    monkeypatch.setenv("FL_DSYEV_JACOBI", "1")
+    n = 96
+    for name, A in _eig_cases(n, 7).items():
+        if name in ("tiny", "huge", "graded"):
+            continue
+        S = np.asfortranarray(np.tril(A))
+        w = np.full(n, np.nan)
+        FL.__linearalgebra_MOD_my_dsyev(b"V", S.ctypes.data_as(dp), w.ctypes.data_as(dp), C.byref(C.c_int(n)), C.c_int(1))
+        norm = max(np.abs(A).sum(axis=1).max(), 1e-300)
+        assert np.abs(A @ S - S * w[None, :]).max() <= 1e-12 * norm and np.abs(S.T @ S - np.eye(n)).max() <= 1e-12, name
+
+
 def test_blocked_cholesky_a_failing_matrix_in_the_middle_of_a_batch_disturbs_nothing():
     """n = 600 (blocked multi-workgroup path): matrix 2 of 5 is indefinite from its 3rd 64-column block on.  The others
     are solved as if it were not there; the failing one reports LAPACK's info, keeps its right-hand side, has its first

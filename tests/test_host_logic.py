@@ -37,7 +37,8 @@ def test_c_abi_library_exports_every_declared_symbol():
         assert hasattr(lib, nme), nme
     # LinearAlgebra symbols the reference's C++ header binds (cpp/FortranLibrary.hpp:48-63)
     for nme in ("__linearalgebra_MOD_my_dgemm", "__linearalgebra_MOD_my_dgemm_t", "__linearalgebra_MOD_my_dsyev",
-                "linearalgebra_mp_my_dgemm_t_", "linearalgebra_mp_my_dsyev_", "fl_dsysv_batched"):
+                "linearalgebra_mp_my_dgemm_t_", "linearalgebra_mp_my_dsyev_", "fl_dsysv_batched", "fl_dsyev_values",
+                "fl_dsyev_vectors", "fl_dsyev_vectors_workspace_bytes", "fl_dsyev_jacobi"):
         assert hasattr(lib, nme), nme
     # import-time symbols of the reference's Python package (FortranLibrary/General.py:4-16)
     for nme in ("__general_MOD_showtime", "general_mp_showtime_", "__general_MOD_dscientificnotation", "general_mp_dscientificnotation_"):
