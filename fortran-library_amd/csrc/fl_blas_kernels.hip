@@ -350,15 +350,21 @@ __global__ void jacobi_diag_kernel(int n, const double *A, int ld, double *w)
 // updated) so that every access is a contiguous column.
 //   vbuf / pbuf [2][n]: reflector and product of the previous / this step (double buffered), scal [2][2]: tau
 //   dyn. LDS: 3 n + 16 doubles (w_{k-1}, v_{k-1}, v_k, reduction scratch)
-__device__ __forceinline__ double wg256_sum(double v, double *scratch)
+template <int BS> __device__ __forceinline__ double wg_sum(double v, double *scratch)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
     __syncthreads(); // scratch free again
     if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
     __syncthreads();
-    return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < BS / 64; q += 4) t += (scratch[q] + scratch[q + 1]) + (scratch[q + 2] + scratch[q + 3]);
+    return t;
 }
-__global__ __launch_bounds__(256) void tridiag_step_kernel(int n, int k, double *A, int ld, const double *vprev,
+// BS = 256 threads per workgroup, or 1024 for large n: the three vectors of a step fill the LDS of a CU from n ~ 3000 on
+// (one workgroup per CU), and what bounds a step then is the bytes its waves keep in flight -- sixteen waves instead of four.
+template <int BS>
+__global__ __launch_bounds__(BS) void tridiag_step_kernel(int n, int k, double *A, int ld, const double *vprev,
                                                            const double *pprev, const double *tauprev, double *vnext,
                                                            double *pnext, double *taunext, double *dvec, double *evec,
                                                            double *tauvec, double *Vkeep, int ldk)
@@ -369,7 +375,7 @@ __global__ __launch_bounds__(256) void tridiag_step_kernel(int n, int k, double 
     const bool first = (k == 0);
     const double *colk = A + (size_t)k * ld;
     const int m = n - k - 1; // rows / columns of the trailing matrix T_k
-    const int lane = tid & 63, gw = blockIdx.x * 4 + (tid >> 6), nwv = gridDim.x * 4;
+    const int lane = tid & 63, gw = blockIdx.x * (BS / 64) + (tid >> 6), nwv = gridDim.x * (BS / 64);
     // 0. Everything this workgroup reads first -- its share of v_{k-1}, p_{k-1}, of column k and the first rows of its
     //    first trailing column -- is requested NOW, before anything waits: the step is a chain of dependent O(m) phases
     //    and one memory round trip instead of four is most of what a step costs (n = 1024: 7.5 -> see DESIGN.md 8).
@@ -379,7 +385,7 @@ __global__ __launch_bounds__(256) void tridiag_step_kernel(int n, int k, double 
     double pf_v[PF], pf_p[PF], pf_c[PF], pf_a[PFA];
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
-        const int r = tid + 256 * j;
+        const int r = tid + BS * j;
         pf_v[j] = vprev[r < mp ? r : mp - 1];
         pf_p[j] = pprev[r < mp ? r : mp - 1];
         pf_c[j] = colk[k + 1 + (r < m ? r : m - 1)];
@@ -395,22 +401,22 @@ __global__ __launch_bounds__(256) void tridiag_step_kernel(int n, int k, double 
         double s = 0.0;
 #pragma unroll
         for (int j = 0; j < PF; ++j) {
-            const int r = tid + 256 * j;
+            const int r = tid + BS * j;
             if (r < mp) {
                 vv[r] = pf_v[j];
                 w[r] = pf_p[j]; // (p for now)
                 s += pf_p[j] * pf_v[j];
             }
         }
-        for (int r = tid + 256 * PF; r < mp; r += 256) {
+        for (int r = tid + BS * PF; r < mp; r += BS) {
             const double vr = vprev[r], pr = pprev[r];
             vv[r] = vr;
             w[r] = pr;
             s += pr * vr;
         }
-        s = wg256_sum(s, scr);
+        s = wg_sum<BS>(s, scr);
         const double alpha = -0.5 * tauprev[0] * s;
-        for (int r = tid; r < mp; r += 256) w[r] = w[r] + alpha * vv[r];
+        for (int r = tid; r < mp; r += BS) w[r] = w[r] + alpha * vv[r];
         __syncthreads();
         w0 = w[0];
         v0 = vv[0];
@@ -420,7 +426,7 @@ __global__ __launch_bounds__(256) void tridiag_step_kernel(int n, int k, double 
         if (tauvec && blockIdx.x == 0) {
             double *keep = Vkeep + (size_t)(k - 1) * ldk + k;
             const double st = sqrt(tauprev[0]);
-            for (int r = tid; r < mp; r += 256) keep[r] = st * vv[r];
+            for (int r = tid; r < mp; r += BS) keep[r] = st * vv[r];
             if (tid == 0) tauvec[k - 1] = tauprev[0];
         }
     }
@@ -428,7 +434,7 @@ __global__ __launch_bounds__(256) void tridiag_step_kernel(int n, int k, double 
     double nrm2 = 0.0;
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
-        const int r = tid + 256 * j;
+        const int r = tid + BS * j;
         if (r < m) {
             double x = pf_c[j];
             if (!first) x = x - (vv[r + 1] * w0 + w[r + 1] * v0);
@@ -436,13 +442,13 @@ __global__ __launch_bounds__(256) void tridiag_step_kernel(int n, int k, double 
             if (r > 0) nrm2 += x * x;
         }
     }
-    for (int r = tid + 256 * PF; r < m; r += 256) {
+    for (int r = tid + BS * PF; r < m; r += BS) {
         double x = colk[k + 1 + r];
         if (!first) x = x - (vv[r + 1] * w0 + w[r + 1] * v0);
         vn[r] = x;
         if (r > 0) nrm2 += x * x;
     }
-    nrm2 = wg256_sum(nrm2, scr);
+    nrm2 = wg_sum<BS>(nrm2, scr);
     const double alpha0 = vn[0];
     double tau = 0.0, beta = alpha0, scale = 0.0;
     if (nrm2 > 0.0) {
@@ -452,10 +458,10 @@ __global__ __launch_bounds__(256) void tridiag_step_kernel(int n, int k, double 
         scale = 1.0 / (alpha0 - beta);
     }
     __syncthreads(); // every thread has read vn[0]
-    for (int r = tid; r < m; r += 256) vn[r] = (r == 0) ? 1.0 : vn[r] * scale;
+    for (int r = tid; r < m; r += BS) vn[r] = (r == 0) ? 1.0 : vn[r] * scale;
     __syncthreads();
     if (blockIdx.x == 0) {
-        for (int r = tid; r < m; r += 256) vnext[r] = vn[r];
+        for (int r = tid; r < m; r += BS) vnext[r] = vn[r];
         if (tid == 0) {
             double dk = colk[k];
             if (!first) dk = dk - 2.0 * (v0 * w0);
@@ -713,9 +719,10 @@ int fl_sytrd_values(int n, double *A_dev, double *w_dev, double *ws, double *tau
     hipStream_t st = static_cast<hipStream_t>(stream);
     double *vbuf = ws, *pbuf = ws + 2 * (size_t)n, *tau = ws + 4 * (size_t)n, *dvec = tau + 4, *evec = dvec + n;
     const size_t lds_step = ((size_t)3 * n + 16) * sizeof(double), lds_sturm = (size_t)2 * n * sizeof(double);
+    const bool wide = n >= 3072; // (see tridiag_step_kernel; n = 2048: 22.5 ms with 256 threads, 28.4 with 1024; n = 4096: 134 / 110)
     if (lds_step > 48 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void *>(fl::tridiag_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds_step) != hipSuccess)
+        hipFuncSetAttribute(wide ? reinterpret_cast<const void *>(fl::tridiag_step_kernel<1024>) : reinterpret_cast<const void *>(fl::tridiag_step_kernel<256>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step) != hipSuccess)
         return FL_ERR_LAUNCH;
     if (lds_sturm > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(fl::sturm_multisection_kernel),
@@ -724,11 +731,19 @@ int fl_sytrd_values(int n, double *A_dev, double *w_dev, double *ws, double *tau
     hipLaunchKernelGGL(fl::symmetrize_kernel, dim3(n), dim3(256), 0, st, n, A_dev, n);
     for (int k = 0; k + 1 < n; ++k) {
         const int m = n - k - 1, cur = k & 1, prv = cur ^ 1;
-        int wgs = (m + 3) / 4; // a column per wave, at most two workgroups per CU (every workgroup repeats the O(m) part)
-        wgs = wgs < 1 ? 1 : (wgs > 512 ? 512 : wgs);
-        hipLaunchKernelGGL(fl::tridiag_step_kernel, dim3(wgs), dim3(256), lds_step, st, n, k, A_dev, n, vbuf + (size_t)prv * n,
-                           pbuf + (size_t)prv * n, tau + prv, vbuf + (size_t)cur * n, pbuf + (size_t)cur * n, tau + cur, dvec,
-                           evec, tauvec, Vkeep, ldk);
+        if (wide) {
+            int wgs = (m + 15) / 16; // a column per wave
+            wgs = wgs < 1 ? 1 : (wgs > 512 ? 512 : wgs);
+            hipLaunchKernelGGL(fl::tridiag_step_kernel<1024>, dim3(wgs), dim3(1024), lds_step, st, n, k, A_dev, n, vbuf + (size_t)prv * n,
+                               pbuf + (size_t)prv * n, tau + prv, vbuf + (size_t)cur * n, pbuf + (size_t)cur * n, tau + cur, dvec, evec,
+                               tauvec, Vkeep, ldk);
+        } else {
+            int wgs = (m + 3) / 4; // a column per wave, at most two workgroups per CU (every workgroup repeats the O(m) part)
+            wgs = wgs < 1 ? 1 : (wgs > 512 ? 512 : wgs);
+            hipLaunchKernelGGL(fl::tridiag_step_kernel<256>, dim3(wgs), dim3(256), lds_step, st, n, k, A_dev, n, vbuf + (size_t)prv * n,
+                               pbuf + (size_t)prv * n, tau + prv, vbuf + (size_t)cur * n, pbuf + (size_t)cur * n, tau + cur, dvec, evec,
+                               tauvec, Vkeep, ldk);
+        }
     }
     // the last diagonal entry took its final update in the last step's column pass (n = 1: the matrix itself)
     hipLaunchKernelGGL(fl::sturm_multisection_kernel, dim3((n + 3) / 4), dim3(256), lds_sturm, st, n, dvec, evec,
