@@ -28,6 +28,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+
 #include "../../include/fl_nlopt.h"
 #include "fl_host.hpp"
 
@@ -161,6 +163,150 @@ __global__ __launch_bounds__(WGM * WGN * 64) void dgemm_kernel(GemmArgs g)
         if (more) lstore(buf ^ 1);
         __syncthreads();
         buf ^= 1;
+    }
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + 16 * TI * wi + 16 * i + lq + 4 * r;
+            if (n < N) {
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    const int m = m0 + 16 * TJ * wj + 16 * j + lr;
+                    if (m < M) {
+                        double *cp = C + (size_t)n * ldc + m;
+                        *cp = (g.beta == 0.0) ? g.alpha * acc[i][j][r] : g.alpha * acc[i][j][r] + g.beta * *cp;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// The same product for SMALL problems (fewer than two 64-tiles per CU: n <= 1024 for one matrix).  There the kernel above
+// is bound by latency, not by the matrix cores: one k-block of MFMAs (0.1-0.2 us) per global-load round trip (~1.3 us), the
+// next block's loads being issued only one block ahead -- n = 1024: 97 us = 64 k-blocks x 1.5 us, whatever the tile.
+// Here the operand loads run ST k-blocks ahead through a ring of staging registers (unrolled, so the ring's slots are
+// registers), unconditionally (beyond K: the last block again, never used; edge tiles: clamped addresses x a 0 / 1 mask
+// -- a load under a test, or a select on its result, is followed by s_waitcnt vmcnt(0) and would undo the distance),
+// and the tiles are 32 x 32 for two waves (1024 workgroups at n = 1024: eight waves per CU instead of four).  Measured
+// (profiles/r03/dgemm_small.txt): n = 256: 23.4 -> 14.0 us, 512: 43.7 -> 25.1, 768: 73.4 -> 51.0, 1024: 96.0 -> 70.1 us
+// (22.4 -> 30.6 TFLOP/s); ST = 2 / 4: 83 / 92 us; the same ring on 64-tiles: 103 us.  What is left per k-block (1.1 us) is
+// the two dependent MFMA chains of a wave and the barrier, not the loads.
+template <int BT, int WGM, int WGN, int ST>
+__global__ __launch_bounds__(WGM * WGN * 64) void dgemm_small_kernel(GemmArgs g)
+{
+    const int transA = g.transA, transB = g.transB, M = g.M, K = g.K, N = g.N, lda = g.lda, ldb = g.ldb, ldc = g.ldc;
+    const double *A = g.A + (size_t)blockIdx.y * g.strideA, *B = g.B + (size_t)blockIdx.y * g.strideB;
+    double *C = g.C + (size_t)blockIdx.y * g.strideC;
+    constexpr int DBM = BT, DBN = BT;
+    constexpr int NT = WGM * WGN * 64;
+    constexpr int TI = DBN / 16 / WGM, TJ = DBM / 16 / WGN;
+    constexpr int TPR = BT / 4;
+    static_assert(NT == 4 * BT, "staging: 16 x BT doubles per operand and k-block, 4 per thread");
+    __shared__ __attribute__((aligned(16))) double As[2][DBK][DBM + DPAD];
+    __shared__ __attribute__((aligned(16))) double Bs[2][DBK][DBN + DPAD];
+    const int tiles_m = (M + DBM - 1) / DBM;
+    const int tm = blockIdx.x % tiles_m, tn = blockIdx.x / tiles_m;
+    const int m0 = tm * DBM, n0 = tn * DBN;
+    if (g.lower && m0 + DBM <= n0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave / WGN, wj = wave % WGN;
+    const int lr = lane & 15, lq = lane >> 4;
+    f64x4 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+    const int nkb = (K + DBK - 1) / DBK;
+    const bool plain = (m0 + DBM <= M) && (n0 + DBN <= N) && (K % DBK == 0); // nothing of this tile's operands is out of range
+    double a_st[ST][4], b_st[ST][4];
+    // operand X: idx_contiguous: element (idx, k) at idx + k*ld, else at k + idx*ld; the thread's four consecutive doubles
+    auto gload_one = [&](const double *X, int ld, bool idx_contiguous, int idx0, int IDX, int k0, double(&st)[4]) {
+        if (idx_contiguous) {
+            const int k = k0 + tid / TPR, i0 = idx0 + (tid % TPR) * 4;
+            if (plain) {
+                const double *q = X + (size_t)k * ld + i0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) st[u] = q[u];
+            } else {
+                const int kc = k < K ? k : K - 1;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u, ic = i < IDX ? i : IDX - 1;
+                    st[u] = X[(size_t)kc * ld + ic] * ((k < K && i < IDX) ? 1.0 : 0.0);
+                }
+            }
+        } else {
+            const int i = idx0 + (tid >> 2), kb = k0 + (tid & 3) * 4;
+            if (plain) {
+                const double *q = X + (size_t)i * ld + kb;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) st[u] = q[u];
+            } else {
+                const int ic = i < IDX ? i : IDX - 1;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = kb + u, kc = k < K ? k : K - 1;
+                    st[u] = X[(size_t)ic * ld + kc] * ((k < K && i < IDX) ? 1.0 : 0.0);
+                }
+            }
+        }
+    };
+    auto gload = [&](int kb, double(&sa)[4], double(&sb)[4]) { // k-block kb (beyond the last: the last again, never used)
+        const int k0 = (kb < nkb ? kb : nkb - 1) * DBK;
+        gload_one(A, lda, !transA, m0, M, k0, sa);
+        gload_one(B, ldb, transB != 0, n0, N, k0, sb);
+    };
+    auto lstore = [&](int buf, const double(&sa)[4], const double(&sb)[4]) {
+        if (!transA) {
+            const int kk = tid / TPR, mm = (tid % TPR) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) As[buf][kk][mm + u] = sa[u];
+        } else {
+            const int mm = tid >> 2, kk = (tid & 3) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) As[buf][kk + u][mm] = sa[u];
+        }
+        if (transB) {
+            const int kk = tid / TPR, nn = (tid % TPR) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) Bs[buf][kk][nn + u] = sb[u];
+        } else {
+            const int nn = tid >> 2, kk = (tid & 3) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) Bs[buf][kk + u][nn] = sb[u];
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < ST; ++s) gload(s, a_st[s], b_st[s]);
+    lstore(0, a_st[0], b_st[0]);
+    __syncthreads();
+    int buf = 0;
+    for (int kb = 0; kb < nkb; kb += ST) {
+#pragma unroll
+        for (int s = 0; s < ST; ++s) { // block kb + s is in LDS[buf]; slot s is free, slots s+1 ... hold the blocks after it
+            if (kb + s < nkb) {
+                gload(kb + s + ST, a_st[s], b_st[s]);
+#pragma unroll
+                for (int ks = 0; ks < DBK / 4; ++ks) {
+                    const int kk = 4 * ks + lq;
+                    double fi[TI], fj[TJ];
+#pragma unroll
+                    for (int i = 0; i < TI; ++i) fi[i] = Bs[buf][kk][16 * TI * wi + 16 * i + lr];
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) fj[j] = As[buf][kk][16 * TJ * wj + 16 * j + lr];
+#pragma unroll
+                    for (int i = 0; i < TI; ++i)
+#pragma unroll
+                        for (int j = 0; j < TJ; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fi[i], fj[j], acc[i][j], 0, 0, 0);
+                }
+                if (kb + s + 1 < nkb) lstore(buf ^ 1, a_st[(s + 1) % ST], b_st[(s + 1) % ST]);
+                __syncthreads();
+                buf ^= 1;
+            }
+        }
     }
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
@@ -626,10 +772,14 @@ int fl_dgemm_strided(int transA, int transB, int M, int K, int N, double alpha, 
         gc.A = g.A + (size_t)b0 * strideA;
         gc.B = g.B + (size_t)b0 * strideB;
         gc.C = g.C + (size_t)b0 * strideC;
+        const int tiles32 = ((M + 31) / 32) * ((N + 31) / 32);
+        hipStream_t st_ = static_cast<hipStream_t>(stream);
         if (big)
-            hipLaunchKernelGGL((fl::dgemm_kernel<128, 2, 4>), dim3(tiles128, nb), dim3(512), 0, static_cast<hipStream_t>(stream), gc);
-        else
-            hipLaunchKernelGGL((fl::dgemm_kernel<64, 2, 2>), dim3(tiles64, nb), dim3(256), 0, static_cast<hipStream_t>(stream), gc);
+            hipLaunchKernelGGL((fl::dgemm_kernel<128, 2, 4>), dim3(tiles128, nb), dim3(512), 0, st_, gc);
+        else if ((long long)tiles64 * nb >= 512) // (n = 1536: 227 us here, 312 with the small-problem kernel on 64-tiles)
+            hipLaunchKernelGGL((fl::dgemm_kernel<64, 2, 2>), dim3(tiles64, nb), dim3(256), 0, st_, gc);
+        else // fewer than two 64-tiles per CU: 32-tiles, operand loads eight k-blocks ahead (dgemm_small_kernel)
+            hipLaunchKernelGGL((fl::dgemm_small_kernel<32, 1, 2, 8>), dim3(tiles32, nb), dim3(128), 0, st_, gc);
     }
     return fl::launch_status();
 }
