@@ -576,10 +576,10 @@ int fl_dsyev_vectors(int n, double *A_dev, int lda, double *w_dev, void *workspa
     else if (n <= 1536) FL_BT(1, 24, 1, 2);
     else if (n <= 1792) FL_BT(1, 28, 1, 2);
     else if (n <= 2048) FL_BT(1, 32, 1, 2);
-    else if (n <= 3072) FL_BT(4, 12, 1, 4);
-    else if (n <= 4096) FL_BT(4, 16, 1, 4);
-    else if (n <= 5120) FL_BT(4, 20, 1, 2);
-    else FL_BT(4, 24, 1, 2);
+    else if (n <= 3072) FL_BT(4, 12, 2, 4); // (beyond 2048: four waves per vector and TWO vectors per workgroup -- there the
+    else if (n <= 4096) FL_BT(4, 16, 2, 4); //  reflectors' L2 traffic binds: n = 4096: 18.3 -> 10.6 ms)
+    else if (n <= 5120) FL_BT(4, 20, 2, 2);
+    else FL_BT(4, 24, 2, 2);
 #undef FL_BT
     if (fl::launch_status() != FL_OK) return FL_ERR_LAUNCH;
     if (hipMemcpyAsync(A_dev, Z, sizeof(double) * nn, hipMemcpyDeviceToDevice, st) != hipSuccess) return FL_ERR_LAUNCH;
