@@ -536,6 +536,7 @@ __global__ __launch_bounds__(BS) void tridiag_step_kernel(int n, int k, double *
         pf_p[j] = pprev[r < mp ? r : mp - 1];
         pf_c[j] = colk[k + 1 + (r < m ? r : m - 1)];
     }
+    const double dk_raw = colk[k]; // (the diagonal entry block 0 reports below: requested with the rest, not after phase 2)
     {
         const double *col0 = A + (size_t)(k + 1 + (gw < m ? gw : m - 1)) * ld + (k + 1);
 #pragma unroll
@@ -609,7 +610,7 @@ __global__ __launch_bounds__(BS) void tridiag_step_kernel(int n, int k, double *
     if (blockIdx.x == 0) {
         for (int r = tid; r < m; r += BS) vnext[r] = vn[r];
         if (tid == 0) {
-            double dk = colk[k];
+            double dk = dk_raw;
             if (!first) dk = dk - 2.0 * (v0 * w0);
             dvec[k] = dk;
             evec[k] = beta;
