@@ -56,11 +56,21 @@ __device__ __forceinline__ void atomic_max_nonneg(double *addr, double v)
     atomicMax(reinterpret_cast<unsigned long long *>(addr), (unsigned long long)__double_as_longlong(v));
 }
 
-// scal[0] = ||T||_inf, sigma = the shifts: eigenvalue i, moved up where it is closer than 10 eps ||T|| to shift i - 1
-// (sigma_i = max(w_i, sigma_{i-1} + sep): a prefix maximum of w_j - j sep).  One workgroup of 256.
+// scal[0] = ||T||_inf, sigma = the shifts.  Eigenvalues closer than sep = 10 eps ||T|| to their neighbour form a cluster
+// whose shifts are put sep apart (dstein's rule: equal shifts would make every vector of the cluster the same dominant
+// combination).  dstein chains them upwards and orthogonalises as it goes; here nothing is orthogonalised until all
+// vectors exist, so a LARGE cluster must not walk its shifts into the eigenvalues above it -- the null cluster of a
+// numerically rank-deficient matrix (a Hilbert matrix: 370 of 400 eigenvalues within 1e-16 of zero, the next ones at
+// 1e-14, 1e-13, ...) chained upwards put hundreds of shifts next to those, and hundreds of vectors collapsed onto theirs.
+// A cluster is therefore chained to the side where it has the room: upwards if the eigenvalue above it stays more than
+// sep beyond its last shift, else downwards (below the previous cluster's shifts), else upwards as before; and members
+// that are numerically the same eigenvalue share one shift beyond their run instead of taking one sep each (below).
+// One workgroup of 256; dyn. LDS 2 n doubles; the scan over the clusters is sequential (thread 0, in LDS).
 __global__ __launch_bounds__(256) void invit_shift_kernel(int n, const double *w, const double *d, const double *e,
                                                           const double *last_diag, double *sigma, double *scal)
 {
+    extern __shared__ double sh[];
+    double *ws = sh, *sg = sh + n;
     __shared__ double red[256];
     const int tid = threadIdx.x;
     double tn = 0.0;
@@ -68,6 +78,7 @@ __global__ __launch_bounds__(256) void invit_shift_kernel(int n, const double *w
         const double di = (i == n - 1) ? last_diag[0] : d[i];
         const double el = (i > 0) ? fabs(e[i - 1]) : 0.0, er = (i < n - 1) ? fabs(e[i]) : 0.0;
         tn = fmax(tn, fabs(di) + el + er);
+        ws[i] = w[i];
     }
     red[tid] = tn;
     __syncthreads();
@@ -76,21 +87,57 @@ __global__ __launch_bounds__(256) void invit_shift_kernel(int n, const double *w
         __syncthreads();
     }
     tn = red[0];
-    __syncthreads();
-    if (tid == 0) scal[0] = tn;
-    const double sep = 10.0 * EV_EPS * tn;
-    const int ch = (n + 255) / 256, j0 = tid * ch, j1 = (j0 + ch < n) ? j0 + ch : n;
-    double mx = -__builtin_inf();
-    for (int j = j0; j < j1; ++j) mx = fmax(mx, w[j] - j * sep);
-    red[tid] = mx;
-    __syncthreads();
-    double run = -__builtin_inf(); // max of w_j - j sep over the chunks before this one
-    for (int t = 0; t < tid; ++t) run = fmax(run, red[t]);
-    for (int j = j0; j < j1; ++j) {
-        const double tj = w[j] - j * sep;
-        sigma[j] = (tj >= run) ? w[j] : j * sep + run;
-        run = fmax(run, tj);
+    if (tid == 0) {
+        scal[0] = tn;
+        const double sep = 10.0 * EV_EPS * tn, tight = 0.05 * sep;
+        // One cluster i .. j, chained in direction dir (+1 upwards, -1 downwards: the mirror image, values negated and
+        // taken from the top).  Members that are TIGHT to their neighbour (closer than eps ||T|| / 2: numerically the same
+        // eigenvalue) do not take one sep each: the first of such a run keeps the chain's shift, the others SHARE one
+        // shift beyond the run's far end, by D = max(sep, the run's width) -- from there their weights in the solves differ
+        // by at most 2^3, the random starts alone keep the vectors independent, and the run blurs its surroundings by D
+        // only (chained one sep each, 370 null eigenvalues reach 2e-12 ||T|| away and take the genuine small ones in;
+        // sharing a shift INSIDE the run's width makes every vector the combination nearest to it).
+        // Returns the last shift (in the mirrored coordinate for dir = -1); write = false: a dry run.
+        auto chain = [&](int i, int j, int dir, bool write) {
+            const int c = j - i + 1;
+            auto v = [&](int k) { return dir > 0 ? ws[i + k] : -ws[j - k]; };
+            auto set = [&](int k, double x) {
+                if (write) sg[dir > 0 ? i + k : j - k] = dir > 0 ? x : -x;
+            };
+            double prev = v(0);
+            set(0, prev);
+            int k = 1;
+            while (k < c) {
+                if (v(k) - v(k - 1) < tight) {
+                    int r = k;
+                    while (r + 1 < c && v(r + 1) - v(r) < tight) ++r; // the run k-1 .. r
+                    const double shared = fmax(v(r), prev) + fmax(sep, v(r) - v(k - 1));
+                    for (int q = k; q <= r; ++q) set(q, shared);
+                    prev = shared;
+                    k = r + 1;
+                } else {
+                    prev = fmax(v(k), prev + sep);
+                    set(k, prev);
+                    ++k;
+                }
+            }
+            return prev;
+        };
+        int i = 0;
+        while (i < n) {
+            int j = i;
+            while (j + 1 < n && ws[j + 1] - ws[j] < sep) ++j; // the cluster i .. j
+            int dir = 1;
+            if (j > i && j + 1 < n && chain(i, j, 1, false) + sep > ws[j + 1]) { // upwards it would reach the eigenvalue above
+                const double lowest = -chain(i, j, -1, false);
+                if (i == 0 || lowest - sep >= sg[i - 1]) dir = -1;
+            }
+            chain(i, j, dir, true);
+            i = j + 1;
+        }
     }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) sigma[i] = sg[i];
 }
 
 __device__ __forceinline__ double invit_start(unsigned v, unsigned k) // uniform in (-1, 1), a hash of (vector, component)
@@ -497,7 +544,11 @@ int fl_dsyev_vectors(int n, double *A_dev, int lda, double *w_dev, void *workspa
     int rc = fl_sytrd_values(n, A_dev, w_dev, front, tauv, Vk, ldv, stream);
     if (rc != FL_OK) return rc;
     const double t1 = now();
-    hipLaunchKernelGGL(fl::invit_shift_kernel, dim3(1), dim3(256), 0, st, n, w_dev, dvec, evec, last, sigma, scal);
+    const size_t lds_shift = (size_t)2 * n * sizeof(double);
+    if (lds_shift > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(fl::invit_shift_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_shift) != hipSuccess)
+        return FL_ERR_LAUNCH;
+    hipLaunchKernelGGL(fl::invit_shift_kernel, dim3(1), dim3(256), lds_shift, st, n, w_dev, dvec, evec, last, sigma, scal);
     const int ivb = fl::invit_block(n);
     hipLaunchKernelGGL(fl::invit_kernel, dim3((n + ivb - 1) / ivb), dim3(ivb), 0, st, n, dvec, evec, last, sigma, scal, F_ra, F_b, F_d2,
                        F_c, F_sw, Y, 3, 0);

@@ -249,7 +249,14 @@ def _eig_cases(n, seed):
         "near_clusters": (Q * (rep + 1e-13 * rng.standard_normal(n))[None, :]) @ Q.T,        # ... split at the 1e-13 level
         "tiny": 1e-200 * 0.5 * (G + G.T),                                                     # squares underflow / overflow
         "huge": 1e+200 * 0.5 * (G + G.T),
+        # numerically rank deficient: a null cluster of ~n - 20 eigenvalues right below genuine ones at 1e-14, 1e-13, ...
+        # (shifts chained upwards walked into those and hundreds of vectors collapsed: invit_shift_kernel)
+        "hilbert": 1.0 / (np.arange(n)[:, None] + np.arange(n)[None, :] + 1.0),
+        "low_rank": G[:, : max(1, n // 5)] @ G[:, : max(1, n // 5)].T,
     }
+    ar = np.diag(rng.standard_normal(n))
+    ar[-1, :] = ar[:, -1] = rng.standard_normal(n)
+    cases["arrow"] = ar
     return {k: 0.5 * (v + v.T) for k, v in cases.items()}
 
 
@@ -289,7 +296,7 @@ def test_fl_dsyev_vectors_passes_its_own_check_and_reports_it(n):
     dev = torch.device("cuda:0")
     wsb = FL.fl_dsyev_vectors_workspace_bytes(n)
     ws = torch.empty((wsb + 7) // 8, dtype=torch.float64, device=dev)
-    names = ("random", "projector", "near_clusters", "tiny") if n > 1024 else None
+    names = ("random", "projector", "near_clusters", "tiny", "hilbert") if n > 1024 else None
     for name, A in _eig_cases(n, 500 + n).items():
         if names and name not in names:
             continue
