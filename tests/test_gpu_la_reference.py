@@ -318,6 +318,36 @@ def test_fl_dsyev_vectors_passes_its_own_check_and_reports_it(n):
                                C.c_size_t(8), None, None) == -3
 
 
+def test_fl_dsyev_vectors_structured_families_stay_on_the_fast_path():
+    """tools/dsyev_stress.py's ten families (prescribed multiplicities, low rank, Hilbert, arrow, weakly coupled blocks, graded,
+    glued Wilkinson, Toeplitz, clusters at several scales), 80 matrices of n = 2 ... 400: the device-side check never sends
+    one to the Jacobi fallback, residuals and orthogonality at LAPACK's level"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import dsyev_stress as DS
+    FL = _fl()
+    FL.fl_dsyev_vectors_workspace_bytes.restype = C.c_size_t
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(2024)
+    for t in range(80):
+        n = int(rng.choice([2, 3, 5, 8, 17, 33, 64, 65, 100, 129, 200, 257, 400]))
+        A = DS.family(rng, t % 10, n)
+        A = 0.5 * (A + A.T)
+        norm = max(np.abs(A).sum(axis=1).max(), 1e-300)
+        Ad = torch.tensor(np.tril(A).T.copy(), device=dev)
+        w = torch.zeros(n, dtype=torch.float64, device=dev)
+        wsb = FL.fl_dsyev_vectors_workspace_bytes(n)
+        ws = torch.empty((wsb + 7) // 8, dtype=torch.float64, device=dev)
+        q = (C.c_double * 3)()
+        rc = FL.fl_dsyev_vectors(C.c_int(n), C.c_void_p(Ad.data_ptr()), C.c_int(n), C.c_void_p(w.data_ptr()), C.c_void_p(ws.data_ptr()),
+                                 C.c_size_t(wsb), q, None)
+        torch.cuda.synchronize()
+        assert rc == 0, (t, n, list(q))
+        V, wh = Ad.cpu().numpy().T, w.cpu().numpy()
+        assert np.abs(A @ V - V * wh[None, :]).max() <= 1e-13 * norm, (t, n)
+        assert np.abs(V.T @ V - np.eye(n)).max() <= 1e-13, (t, n)
+        assert np.abs(wh - np.linalg.eigvalsh(A)).max() <= 1e-13 * norm, (t, n)
+
+
 def test_my_dsyev_jacobi_on_request(monkeypatch):
     """FL_DSYEV_JACOBI=1: the cyclic Jacobi path (the fallback of the 'V' job) stays reachable and correct"""
     FL = _fl()
