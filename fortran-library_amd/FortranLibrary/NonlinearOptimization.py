@@ -549,6 +549,40 @@ def dgemm(A, B, transA=False):
     return out
 
 
+def dsyev(A, vectors=True):
+    """My_dsyev on a device tensor: A [n, n] symmetric (only what is the LOWER triangle of the column-major matrix is read,
+    i.e. A[j, i] for i >= j), overwritten.  Returns (w, V): the eigenvalues ascending and, with vectors, V [n, n] whose ROW k
+    is the normalised eigenvector k (= column k of the column-major result; V is A itself) -- else (w, None).
+    'V': fl_dsyev_vectors (tridiagonalisation + inverse iteration + Cholesky-QR + back-transformation), cyclic Jacobi when
+    its device-side check of the basis fails; 'N': fl_dsyev_values.  n <= 6144."""
+    import torch
+    n = A.shape[0]
+    assert A.shape == (n, n) and A.dtype == torch.float64 and A.is_contiguous()
+    FL.fl_dsyev_vectors_workspace_bytes.restype = C.c_size_t
+    FL.fl_dsyev_workspace_bytes.restype = C.c_size_t
+    w = torch.empty(n, dtype=torch.float64, device=A.device)
+    wsb = max(FL.fl_dsyev_vectors_workspace_bytes(n) if vectors else 0, FL.fl_dsyev_workspace_bytes(n))
+    ws = torch.empty((wsb + 7) // 8, dtype=torch.float64, device=A.device)
+    if not vectors:
+        _check(FL.fl_dsyev_values(C.c_int(n), C.c_void_p(A.data_ptr()), C.c_int(n), C.c_void_p(w.data_ptr()), C.c_void_p(ws.data_ptr()),
+                                  C.c_size_t(wsb), _stream()), "fl_dsyev_values")
+        return w, None
+    keep = A.clone()
+    rc = FL.fl_dsyev_vectors(C.c_int(n), C.c_void_p(A.data_ptr()), C.c_int(n), C.c_void_p(w.data_ptr()), C.c_void_p(ws.data_ptr()),
+                             C.c_size_t(wsb), None, _stream())
+    if rc == 1:  # the basis did not pass its check: Jacobi on the copy (unsorted: sort here)
+        A.copy_(keep)
+        sweeps = C.c_int(0)
+        _check(FL.fl_dsyev_jacobi(C.c_char(b"V"), C.c_int(n), C.c_void_p(A.data_ptr()), C.c_int(n), C.c_void_p(w.data_ptr()),
+                                  C.c_void_p(ws.data_ptr()), C.c_size_t(wsb), C.c_int(60), C.byref(sweeps), _stream()), "fl_dsyev_jacobi")
+        V = ws[n * n: 2 * n * n].view(n, n)
+        order = torch.argsort(w)
+        A.copy_(V[order])
+        return w[order].contiguous(), A
+    _check(rc, "fl_dsyev_vectors")
+    return w, A
+
+
 def lbfgs_onchip_pairs(objective, n):
     """pairs of the (s, y) ring the fused L-BFGS kernel keeps in registers / LDS for this objective and dimension"""
     FL.fl_lbfgs_onchip_pairs.restype = C.c_int

@@ -348,6 +348,23 @@ def test_fl_dsyev_vectors_structured_families_stay_on_the_fast_path():
         assert np.abs(wh - np.linalg.eigvalsh(A)).max() <= 1e-13 * norm, (t, n)
 
 
+def test_python_dsyev_on_device_tensors():
+    """NonlinearOptimization.dsyev: the device entries behind My_dsyev for a torch tensor (rows of V = eigenvectors)"""
+    NLO = _nlo()
+    dev = torch.device("cuda:0")
+    for n in (7, 300):
+        A = LC.eig_case(n) if n in (5, 64, 200, 1024) else _eig_cases(n, 9)["random"]
+        At = torch.tensor(np.tril(A).T.copy(), device=dev)  # row j of the tensor = column j of the lower triangle
+        w, V = NLO.dsyev(At)
+        torch.cuda.synchronize()
+        wh, Vh = w.cpu().numpy(), V.cpu().numpy()
+        norm = np.abs(A).sum(axis=1).max()
+        assert np.abs(wh - np.linalg.eigvalsh(A)).max() <= 1e-13 * norm
+        assert np.abs(A @ Vh.T - Vh.T * wh[None, :]).max() <= 1e-13 * norm and np.abs(Vh @ Vh.T - np.eye(n)).max() <= 1e-13
+        w2, none = NLO.dsyev(torch.tensor(np.tril(A).T.copy(), device=dev), vectors=False)
+        assert none is None and np.abs(w2.cpu().numpy() - wh).max() <= 1e-13 * norm
+
+
 def test_my_dsyev_jacobi_on_request(monkeypatch):
     """FL_DSYEV_JACOBI=1: the cyclic Jacobi path (the fallback of the 'V' job) stays reachable and correct"""
     FL = _fl()
