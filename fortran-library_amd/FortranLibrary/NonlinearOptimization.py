@@ -611,7 +611,7 @@ def synth_diag_spectrum(seed, out, kappa_lo, kappa_hi):
 def multi_solve(solver, objective, x, d=None, b=None, M=0, lambda0=None, miu0=1.0, nshards=0, interleaved=False, options=None, **kw):
     """A batch of independent problems over all the GPUs of the node from this one process (fl_multi_solve): numpy HOST
     arrays [batch, n] in, x updated in place, one host thread per shard.  M > 0: AugmentedLagrangian with M block-sphere
-    constraints around `solver`.  nshards = 0: one shard per visible device.  Returns the usual per-problem outputs."""
+    constraints around `solver`.  nshards = 0: up to four shards per visible device (their transfers and solves overlap).  Returns the usual per-problem outputs."""
     import numpy as np
     o = options if options is not None else default_options(solver, **kw)
     if not (isinstance(x, np.ndarray) and x.dtype == np.float64 and x.ndim == 2 and x.flags.c_contiguous):

@@ -259,7 +259,8 @@ int fl_augmented_lagrangian_batched(int solver, int objective, int batch, int n,
  *   solver     FL_SOLVER_SD | CG | LBFGS | BFGS | NEWTON;  objective, opt, outputs: as in the one-device entries
  *   aug_m > 0  AugmentedLagrangian around `solver` with aug_m block-sphere constraints (fl_augmented_lagrangian_batched):
  *              lambda_host [batch][aug_m] in (NULL: lambda0 = 0) / out, miu0, cnorm2_host, outer_host; gg_host unused
- *   nshards    <= 0: one shard per visible device; more shards than devices share devices round-robin
+ *   nshards    <= 0: up to four shards per visible device (while a shard keeps >= 4096 problems: the shards of a device
+ *              overlap each other's transfers and solves); more shards than devices share devices round-robin
  *   interleaved  0: contiguous blocks of ceil(batch / nshards) problems;  1: problem k -> shard k mod nshards
  * Every output pointer may be NULL.  Results do not depend on the sharding (one workgroup owns one problem either way). */
 int fl_multi_device_count(void);

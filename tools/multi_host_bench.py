@@ -37,7 +37,7 @@ xd = x.cpu().numpy()
 del d, b, x, ws
 torch.cuda.empty_cache()
 print(json.dumps({"form": "device pointers (what bench.py times)", "ms": dev_ms, "iterations_per_s": it / dev_ms * 1e3}))
-for shards in (1, 2, 4):
+for shards in (0, 1, 2, 4, 8):
     best = 1e9
     for rep in range(2):
         xh = np.zeros((B, n))
@@ -45,5 +45,5 @@ for shards in (1, 2, 4):
         o = NLO.multi_solve(NLO.LBFGS_, NLO.DIAGQUAD, xh, dh, bh, nshards=shards, Precision=1e-6, MaxIteration=3000, Memory=m)
         best = min(best, (time.perf_counter() - t) * 1e3)
     same = bool(np.array_equal(xh, xd) and int(o["iters"].astype(np.int64).sum()) == it)
-    print(json.dumps({"form": f"host arrays, fl_multi_solve, {shards} shard(s) on {NLO.FL.fl_multi_device_count()} GPU(s)", "ms": best,
+    print(json.dumps({"form": f"host arrays, fl_multi_solve, {shards or 'default'} shard(s) on {NLO.FL.fl_multi_device_count()} GPU(s)", "ms": best,
                       "iterations_per_s": it / best * 1e3, "host_bytes_moved": int(4 * B * n * 8), "same_bits_as_device_form": same}))
