@@ -51,13 +51,17 @@ template <int NW, int EPT> struct Geo {
     static constexpr int T = NW * 64;
     static constexpr int NPAD = T * EPT;
     static constexpr int NCH = EPT / 2;
+    // The thread's index INSIDE ITS PROBLEM'S GROUP of T threads.  A workgroup normally is one such group (the mask folds
+    // away: the compiler knows threadIdx.x < T from the launch bounds); the replicated kernels (fl_solve_rep_kernel) run
+    // several identical groups per workgroup, each a full copy of the machine with LDS of its own.
+    __device__ __forceinline__ static int ltid() { return (int)(threadIdx.x & (unsigned)(T - 1)); }
     // The thread index behind an empty asm: index arithmetic derived from it is then redone where it is used
     // (one or two integer instructions) instead of being hoisted out of the solver's main loop and kept -- or
     // spilled -- for the whole kernel.  Measured on the code objects: fl_solve_kernel<2,8,DIAGQUAD,LBFGS> 217 -> 211
     // VGPRs, the 4x8 BFGS kernels 12-44 spilled VGPRs -> 0.
     __device__ __forceinline__ static int tid()
     {
-        int t = threadIdx.x;
+        int t = ltid();
         asm volatile("" : "+v"(t));
         return t;
     }
@@ -112,7 +116,7 @@ template <int NW, int EPT> __device__ __forceinline__ void load_pad(const double
 {
     using G = Geo<NW, EPT>;
     if constexpr (NW <= FL_SADDR) {
-        const unsigned off = threadIdx.x * 16u;
+        const unsigned off = (unsigned)G::ltid() * 16u;
         const char *base = reinterpret_cast<const char *>(row);
 #pragma unroll
         for (int c = 0; c < G::NCH; ++c) {
@@ -133,7 +137,7 @@ template <int NW, int EPT> __device__ __forceinline__ void store_pad(double *row
 {
     using G = Geo<NW, EPT>;
     if constexpr (NW <= FL_SADDR) {
-        const unsigned off = threadIdx.x * 16u;
+        const unsigned off = (unsigned)G::ltid() * 16u;
         char *base = reinterpret_cast<char *>(row);
 #pragma unroll
         for (int c = 0; c < G::NCH; ++c)
@@ -246,7 +250,7 @@ template <int NW, int EPT> struct Objective<FL_OBJ_ROSENBROCK, NW, EPT> {
     static constexpr int LDS_DOUBLES = G::NPAD + 2;
     __device__ __forceinline__ void init(const SolveArgs &, int, double *xs)
     {
-        if (threadIdx.x == 0) {
+        if (G::ltid() == 0) {
             xs[0] = 0.0;
             xs[G::NPAD + 1] = 0.0;
         }
@@ -754,7 +758,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
                 R.run(q);
                 r2[0] = q[0];
                 r2[1] = q[1];
-                if (threadIdx.x == 0) {
+                if (G::ltid() == 0) {
 #pragma unroll
                     for (int u = 0; u < 8; ++u) cxs[u] = q[2 + u] - 1.0;
                 }
@@ -767,7 +771,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
 #pragma unroll
                         for (int u = 0; u < 4; ++u) q[u] = cpart(j0 + u);
                         R.run(q);
-                        if (threadIdx.x == 0) {
+                        if (G::ltid() == 0) {
 #pragma unroll
                             for (int u = 0; u < 4; ++u) cxs[j0 + u] = q[u] - 1.0;
                         }
@@ -832,7 +836,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
     }
     // fs[k] = L(x0 + as[k] p), k < K, for given step lengths.  x, g are not touched.  CS = cshift (a template parameter so
     // that the whole pass is straight-line code: the reductions of different chunks and trials interleave).
-    template <int K, int CS> __device__ __forceinline__ void evaluate_spec(const double (&as)[K], double (&fs)[K])
+    template <int K, int CS> __device__ __forceinline__ void evaluate_spec(const double (&as)[K], double (&fs)[K], const double *x0row)
     {
         static_assert(AUG, "objective-only trials exist in the augmented-Lagrangian kernels only");
         const int m = A.aug_m;
@@ -843,7 +847,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
             double xb[EPT];
             if constexpr (X0_LDS) { // x0 is read from its LDS row again for every trial (FL_SPEC_X0_RELOAD): 16 VGPRs
                                     // less across the pass, which is what lets four trials fit three waves per SIMD
-                load_pad<NW, EPT>(lds + L_X0, xb);
+                load_pad<NW, EPT>(x0row, xb);
                 if constexpr (FL_SPEC_X0_RELOAD) asm volatile("" ::: "memory");
             }
 #pragma unroll
@@ -923,7 +927,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
             an[0] = next(as[K - 1]);
 #pragma unroll
             for (int k = 1; k < K; ++k) an[k] = next(an[k - 1]);
-            evaluate_spec<K, CS>(as, fs);
+            evaluate_spec<K, CS>(as, fs, lds + L_X0);
             unsigned exits = 0; // bit k: the reference leaves the loop at trial k (Armijo holds, or a < 1e-15)
 #pragma unroll
             for (int k = 0; k < K; ++k) {
@@ -964,6 +968,151 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
 #pragma unroll
         for (int k = 0; k < EPT; ++k) asm volatile("" : "=v"(g[k]));
         return uni(f_x);
+    }
+    // The same loop TRIAL-PARALLEL over the REP waves of a workgroup (fl_solve_rep_kernel; round 4).  A batch that
+    // under-fills the chip -- one GPU's share of BASELINE config 5 on eight GPUs: 1024 problems for 1024 SIMDs -- is bound by
+    // its slowest problem, and that problem's time is this loop (profiles/r04/phase_timers_c5.txt: 58 of 72 ms; the reference
+    // walks a <- a / 1.05 hundreds of steps after every restart of the inner solver).  More waves per problem in the usual way
+    // (elements over waves) shorten a trial only by its element-wise part and change the summation order.  Instead wave 0 (the
+    // MASTER) runs the machine as fl_solve_kernel does, with every element of the problem in its registers, and REP - 1 HELPER
+    // waves hold the objective's data and wait at the workgroup barrier; in this loop wave r evaluates trials r K .. r K + K - 1
+    // of each pass of REP K consecutive step lengths.  Every trial is summed inside ONE wave exactly as the unhelped kernel
+    // sums it, so the result -- minimiser, counts, every bit -- is that of the throughput geometry: the helpers are invisible
+    // to the caller and to the oracle.  Per pass the waves exchange (a, f) of their trials and their exit bits through LDS (two
+    // alternating buffers, one barrier); the chain of divisions a_(t+1) = a_t / incrmt is walked by every wave in full (its
+    // roundings are part of the reference's arithmetic).  A helper skips the epilogue (the machine is the master's).
+#ifndef FL_WIDE_CHAIN_FIRST
+#define FL_WIDE_CHAIN_FIRST 1
+#endif
+    template <int K, int CS, int REP> __device__ __forceinline__ double fast_forward_wide_cs(double *xch, int rep, const double *x0row, bool master)
+    {
+        constexpr int W = K * REP;
+        int *xmask = reinterpret_cast<int *>(xch + 4 * W); // [2][REP]
+        auto next = [&](double a_) { return uni(a_ / ls.incr); };
+        double as[K];
+        {
+            double c = ls.a_eval;
+            for (int i = 0; i < rep * K; ++i) c = next(c);
+            as[0] = c;
+#pragma unroll
+            for (int k = 1; k < K; ++k) as[k] = next(as[k - 1]);
+        }
+        double aold = ls.aold, fold = ls.fold, a_x = 0.0, f_x = 0.0;
+        int consumed = 0, par = 0;
+        for (;;) {
+            double an[K], fs[K]; // the wave's step lengths of the next pass: W - K + 1 divisions on from its last one
+#if FL_WIDE_CHAIN_FIRST
+            {
+                double c = as[K - 1];
+#pragma unroll
+                for (int i = 0; i < W - K + 1; ++i) c = next(c);
+                an[0] = c;
+#pragma unroll
+                for (int k = 1; k < K; ++k) an[k] = next(an[k - 1]);
+            }
+#endif
+            evaluate_spec<K, CS>(as, fs, x0row);
+#if !FL_WIDE_CHAIN_FIRST
+            {
+                double c = as[K - 1];
+#pragma unroll
+                for (int i = 0; i < W - K + 1; ++i) c = next(c);
+                an[0] = c;
+#pragma unroll
+                for (int k = 1; k < K; ++k) an[k] = next(an[k - 1]);
+            }
+#endif
+            unsigned mine = 0; // bit k: the reference leaves the loop at this wave's trial k (Armijo holds, or a < 1e-15)
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const double bound = ls.fx0 + ls.c1 * as[k] * ls.phid0;
+                mine |= (unsigned)((fs[k] <= bound) | (as[k] < 1e-15)) << k;
+            }
+            double *buf = xch + par * (2 * W);
+            if (G::ltid() == 0) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    buf[2 * (rep * K + k)] = as[k];
+                    buf[2 * (rep * K + k) + 1] = fs[k];
+                }
+                xmask[par * REP + rep] = (int)mine;
+            }
+            __syncthreads();
+            unsigned exits = 0;
+#pragma unroll
+            for (int r = 0; r < REP; ++r) exits |= (unsigned)xmask[par * REP + r] << (r * K);
+            exits = __builtin_amdgcn_readfirstlane(exits);
+            if (exits) {
+                if (master) {
+                    const int kx = __builtin_ctz(exits);
+                    a_x = buf[2 * kx];
+                    f_x = buf[2 * kx + 1];
+                    if (kx > 0) {
+                        aold = buf[2 * kx - 2];
+                        fold = buf[2 * kx - 1];
+                    } else if (consumed > 0) { // the last trial of the previous pass (the other buffer: not rewritten yet)
+                        const double *prev = xch + (par ^ 1) * (2 * W);
+                        aold = prev[2 * W - 2];
+                        fold = prev[2 * W - 1];
+                    }
+                    consumed += kx;
+                }
+                break;
+            }
+            consumed += W;
+            par ^= 1;
+#pragma unroll
+            for (int k = 0; k < K; ++k) as[k] = an[k];
+        }
+        double fr = 0.0;
+        if (master) {
+            ls.a = ls.a_eval = uni(a_x);
+            ls.aold = uni(aold);
+            ls.fold = uni(fold);
+            nf += consumed;
+            move(ls.a_eval);
+            fr = uni(f_x);
+        } else { // (a helper's x is never read: undefined here, so that it does not occupy registers across the loop)
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) asm volatile("" : "=v"(x[k]));
+        }
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) asm volatile("" : "=v"(g[k])); // (as in fast_forward_cs: rewritten before it is read)
+        __syncthreads(); // every wave has read the exchange buffers before the next search's first pass rewrites them
+        return fr;
+    }
+    template <int K, int REP> __device__ __forceinline__ double fast_forward_wide(double *xch, int rep, const double *x0row, bool master)
+    {
+        if (cshift == 5) return fast_forward_wide_cs<K, 5, REP>(xch, rep, x0row, master);
+        if (cshift == 6) return fast_forward_wide_cs<K, 6, REP>(xch, rep, x0row, master);
+        return fast_forward_wide_cs<K, 4, REP>(xch, rep, x0row, master);
+    }
+    // what a helper needs of the master's state for one shrink loop: the search direction (a row), the loop's scalars, the
+    // penalty parameter and the multipliers.  pub: [NPAD] p | PUB_SCALARS scalars | [FL_MAX_CONSTRAINTS] lambda
+    static constexpr int PUB_SCALARS = 8;
+    static constexpr int PUB_X0 = X0_LDS ? 0 : NPAD; // x0 too where the master keeps it in registers (else the helpers read its LDS row)
+    static constexpr int PUB_DOUBLES = NPAD + PUB_X0 + PUB_SCALARS + FL_MAX_CONSTRAINTS;
+    __device__ __forceinline__ void publish_search(double *pub)
+    {
+        store_pad<NW, EPT>(pub, p);
+        if constexpr (!X0_LDS) store_pad<NW, EPT>(pub + NPAD, x0);
+        const int tl = G::tid();
+        if (tl == 0) {
+            double *q = pub + NPAD + PUB_X0;
+            q[0] = ls.a_eval; q[1] = ls.incr; q[2] = ls.fx0; q[3] = ls.c1; q[4] = ls.phid0; q[5] = miu;
+        }
+        if (tl < A.aug_m) pub[NPAD + PUB_X0 + PUB_SCALARS + tl] = lds[L_LAM + tl];
+    }
+    __device__ __forceinline__ void helper_take(const double *pub)
+    {
+        load_pad<NW, EPT>(pub, p);
+        if constexpr (!X0_LDS) load_pad<NW, EPT>(pub + NPAD, x0);
+        const double *q = pub + NPAD + PUB_X0;
+        ls.a_eval = uni(q[0]); ls.incr = uni(q[1]); ls.fx0 = uni(q[2]); ls.c1 = uni(q[3]); ls.phid0 = uni(q[4]);
+        miu = uni(q[5]);
+        ls.aold = ls.fold = 0.0;
+        const int tl = G::tid();
+        if (tl < A.aug_m) lds[L_LAM + tl] = pub[NPAD + PUB_X0 + PUB_SCALARS + tl]; // (read back by this wave only: in order)
     }
     template <int K> __device__ __forceinline__ double fast_forward()
     {
@@ -1558,7 +1707,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
             r[1] = dot_part<EPT>(yv, yv);
         }
         R.run(r);
-        if (threadIdx.x == 0) rho_s[recent] = 1.0 / r[0];
+        if (G::ltid() == 0) rho_s[recent] = 1.0 / r[0];
         rho_recent = uni(1.0 / r[0]);
         yy_recent = uni(r[1]);
         __syncthreads(); // rho_s; and the ring rows just stored are read back by the threads that wrote them
@@ -1575,7 +1724,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
             double q[1] = {dot_part<EPT>(row, p)};
             R.run(q);
             const double al = rho_s[sl] * q[0];
-            if (threadIdx.x == 0) alpha_s[sl] = al;
+            if (G::ltid() == 0) alpha_s[sl] = al;
             load_pad<NW, EPT>(hist + (size_t)(2 * sl + 1) * NPAD, row);
 #pragma unroll
             for (int k = 0; k < EPT; ++k) p[k] = p[k] - al * row[k];
@@ -1659,7 +1808,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
         r[0] = dot_part<EPT>(yv, sv);
         r[1] = dot_part<EPT>(yv, yv);
         R.run(r);
-        if (threadIdx.x == 0) rho_s[recent] = 1.0 / r[0]; // rho=1/(y.s): no curvature safeguard (NO.f90:623)
+        if (G::ltid() == 0) rho_s[recent] = 1.0 / r[0]; // rho=1/(y.s): no curvature safeguard (NO.f90:623)
         rho_recent = uni(1.0 / r[0]);
         yy_recent = uni(r[1]);
         __syncthreads();
@@ -1690,7 +1839,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
             double q[1] = {dot_part<EPT>(s_, p)};
             R.run(q);
             const double al = rho_s[sl] * q[0]; // alpha(i)=rho(i)*dot_product(s(:,i),p)
-            if (threadIdx.x == 0) alpha_s[sl] = al;
+            if (G::ltid() == 0) alpha_s[sl] = al;
 #pragma unroll
             for (int k = 0; k < EPT; ++k) p[k] = p[k] - al * y_[k];
         };
@@ -1945,7 +2094,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
             p[k] = -(w[k] - (rho * q[k]) * r3[1] - (rho * sv[k]) * r3[2] + (cs * sv[k]) * r3[1]); // p=-matmul(H,fdnew)
         store_pad<NW, EPT>(D + (size_t)(2 * ndef) * NPAD, sv);
         store_pad<NW, EPT>(D + (size_t)(2 * ndef + 1) * NPAD, q);
-        if (threadIdx.x == 0) {
+        if (G::ltid() == 0) {
             drho[ndef] = rho;
             dcs[ndef] = cs;
         }
@@ -2163,7 +2312,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
             const int tl = G::tid();
             if (tl < A.aug_m) A.lambda[(size_t)prob * A.aug_m + tl] = lds[L_LAM + tl];
         }
-        if (threadIdx.x == 0) {
+        if (G::ltid() == 0) {
             if (A.f_out) A.f_out[prob] = fnew;
             if (A.gg_out) A.gg_out[prob] = gg;
             if (A.iters) A.iters[prob] = iters + inner_iters_total;

@@ -109,7 +109,7 @@ template <int NW> struct Reducer {
         if constexpr (NW > 1) {
             // 512-thread kernels (256 VGPRs per wave): recompute the slot indices here instead of keeping them
             // (or spilling them) across the whole solver loop -- see Geo::tid()
-            int tx = threadIdx.x;
+            int tx = (int)(threadIdx.x & (unsigned)(NW * 64 - 1)); // (index inside the problem's group of NW waves: Geo::ltid())
             if constexpr (NW >= 8) asm volatile("" : "+v"(tx));
             const int lane = tx & 63, wave = tx >> 6;
             double *s = slots + parity * (NVMAX * NW);

@@ -1,0 +1,6 @@
+// latency geometry 4 waves x 2 elements per thread: SD / CG / L-BFGS (+ the augmented Lagrangian around CG / L-BFGS) for
+// batches that under-fill the chip (fl_solver_launch.hpp: launch_lat; fl_solver_kernels.hip: select_fused_geometry)
+#include "fl_solver_launch.hpp"
+namespace fl {
+template hipError_t launch_lat<4, 2>(int, int, int, const SolveArgs &, hipStream_t);
+}

@@ -12,6 +12,26 @@
 //     lock-step batch, no host round trips).
 #include "fl_solver_launch.hpp"
 #include "fl_big.hpp"
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+// break-even batches of the latency geometries (problems per 256 CUs; profiles/r04/geometry_by_batch.txt)
+#ifndef FL_LAT_256_A
+#define FL_LAT_256_A 2048
+#define FL_LAT_512_A 1024
+#define FL_LAT_512_B 3072
+#define FL_LAT_1024_A 512
+#define FL_LAT_1024_B 2048
+#define FL_LAT_2048_A 1024
+#define FL_LAT_AUG_256_A 2048
+#define FL_LAT_AUG_512_A 1024
+#define FL_LAT_AUG_512_B 3072
+#define FL_LAT_AUG_1024_A 512
+#define FL_LAT_AUG_1024_B 2048
+#define FL_LAT_AUG_2048_A 1024
+#endif
 
 
 namespace fl {
@@ -95,7 +115,7 @@ static bool select_geometry(int n, GeoSel &g)
 // every reduction stays inside the wave and the reduction / line-search scalar work is done once instead of twice
 // (C3: 65.4 -> 54.3 ms).  Same padded length threads*ept as the layout geometry of n; L-BFGS (row buffers, ring pairs)
 // and the dense solvers keep 2 x 8, and so do the reverse-communication kernels.
-static bool select_fused_geometry(int n, int method, bool aug, GeoSel &g)
+static bool select_throughput_geometry(int n, int method, bool aug, GeoSel &g)
 {
     if (!select_geometry(n, g)) return false;
     if (!aug && (method == FL_SOLVER_SD || method == FL_SOLVER_CG) && n > 512) g = {g.nw / 2, 16}; // 1 x 16, 2 x 16, 4 x 16
@@ -105,11 +125,142 @@ static bool select_fused_geometry(int n, int method, bool aug, GeoSel &g)
     return true;
 }
 
+// ---- geometry by BATCH (round 4).  The throughput geometries above are tuned for a chip full of problems.  A batch that
+// leaves it under-filled -- one GPU's share of BASELINE config 5 on eight GPUs is 1024 problems for 256 CUs -- is bound by
+// the latency of one problem's trial chain instead, and there more waves x fewer elements per thread win: the element-wise
+// part of every trial shrinks with the elements per thread while the reductions grow only by the cross-wave step.
+// Policy: fl_options.geometry, else the process policy (fl_set_geometry_policy / FL_GEOMETRY in the environment; default
+// FL_GEOMETRY_AUTO).  AUTO takes a latency geometry while batch <= its measured break-even (a table per n range, in
+// problems per 256 CUs, scaled by the device's CU count; profiles/r04/geometry_by_batch.txt).
+static std::atomic<int> g_geometry_policy{-1};
+static int process_geometry_policy()
+{
+    int p = g_geometry_policy.load(std::memory_order_relaxed);
+    if (p >= 0) return p;
+    p = FL_GEOMETRY_AUTO;
+    if (const char *e = getenv("FL_GEOMETRY")) {
+        if (!strcmp(e, "throughput")) p = FL_GEOMETRY_THROUGHPUT;
+        else if (!strcmp(e, "latency")) p = FL_GEOMETRY_LATENCY;
+        else if (!strcmp(e, "auto")) p = FL_GEOMETRY_AUTO;
+    }
+    g_geometry_policy.store(p, std::memory_order_relaxed);
+    return p;
+}
+static int device_compute_units()
+{
+    static std::atomic<int> cus{0};
+    int c = cus.load(std::memory_order_relaxed);
+    if (c > 0) return c;
+    c = 256; // MI355X; also what the geometry queries answer with on a machine without a device
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
+        c = pr.multiProcessorCount;
+    else (void)hipGetLastError();
+    cus.store(c, std::memory_order_relaxed);
+    return c;
+}
+struct LatencyChoice {
+    int nw, ept;
+    int max_batch; // per 256 CUs: AUTO takes this geometry while the batch is at most this
+};
+// candidates of an n range, most waves first (FL_GEOMETRY_LATENCY takes the first)
+static int latency_candidates(int n, int method, bool aug, const LatencyChoice **out)
+{
+    // measured on MI355X (profiles/r04/geometry_by_batch.txt); unconstrained SD / CG / L-BFGS and the augmented Lagrangian
+    // around CG / L-BFGS have tables of their own: the constrained trial chain is longer, so its break-even lies higher
+    static const LatencyChoice c256[] = {{2, 2, FL_LAT_256_A}};
+    static const LatencyChoice c512[] = {{4, 2, FL_LAT_512_A}, {2, 4, FL_LAT_512_B}};
+    static const LatencyChoice c1024[] = {{8, 2, FL_LAT_1024_A}, {4, 4, FL_LAT_1024_B}};
+    static const LatencyChoice c2048[] = {{8, 4, FL_LAT_2048_A}};
+    static const LatencyChoice a256[] = {{2, 2, FL_LAT_AUG_256_A}};
+    static const LatencyChoice a512[] = {{4, 2, FL_LAT_AUG_512_A}, {2, 4, FL_LAT_AUG_512_B}};
+    static const LatencyChoice a1024[] = {{8, 2, FL_LAT_AUG_1024_A}, {4, 4, FL_LAT_AUG_1024_B}};
+    static const LatencyChoice a2048[] = {{8, 4, FL_LAT_AUG_2048_A}};
+    if (method != FL_SOLVER_SD && method != FL_SOLVER_CG && method != FL_SOLVER_LBFGS) return 0;
+    if (aug && method == FL_SOLVER_SD) return 0;
+    if (n <= 128 || n > 2048) return 0;
+#define FL_PICK(T_) do { *out = T_; return (int)(sizeof(T_) / sizeof(T_[0])); } while (0)
+    if (n <= 256) { if (aug) FL_PICK(a256); else FL_PICK(c256); }
+    if (n <= 512) { if (aug) FL_PICK(a512); else FL_PICK(c512); }
+    if (n <= 1024) { if (aug) FL_PICK(a1024); else FL_PICK(c1024); }
+    if (aug) FL_PICK(a2048); else FL_PICK(c2048);
+#undef FL_PICK
+}
+static bool select_fused_geometry(int n, int method, bool aug, int batch, int geometry, GeoSel &g)
+{
+    if (!select_throughput_geometry(n, method, aug, g)) return false;
+#ifdef FL_FORCE_GEO_N
+    return true;
+#endif
+    int policy = (geometry >= FL_GEOMETRY_THROUGHPUT && geometry <= FL_GEOMETRY_AUTO) ? geometry : process_geometry_policy();
+    const LatencyChoice *c = nullptr;
+    const int nc = latency_candidates(n, method, aug, &c);
+    if (nc == 0) return true;
+    if (const char *f = getenv("FL_FORCE_GEOMETRY")) { // tuning knob (tools/geometry_by_batch.py): "4x2" = that candidate of the range
+        int fw = 0, fe = 0;
+        if (sscanf(f, "%dx%d", &fw, &fe) == 2)
+            for (int i = 0; i < nc; ++i)
+                if (c[i].nw == fw && c[i].ept == fe) {
+                    g = {fw, fe};
+                    return true;
+                }
+        return true; // (anything else: the throughput geometry)
+    }
+    if (policy == FL_GEOMETRY_THROUGHPUT) return true;
+    if (policy == FL_GEOMETRY_LATENCY) {
+        g = {c[0].nw, c[0].ept};
+        return true;
+    }
+    const long long scaled = (long long)batch * 256 / device_compute_units(); // the batch as a 256-CU device would see it
+    for (int i = 0; i < nc; ++i)
+        if (scaled <= c[i].max_batch) {
+            g = {c[i].nw, c[i].ept};
+            return true;
+        }
+    return true;
+}
+
+// Replicated groups (fl_solve_rep_kernel): how many complete copies of the machine share a problem's objective-only shrink
+// loop.  Only where that loop runs as a tight loop at all (Solver::spec_shrinking: augmented Lagrangian around L-BFGS / CG,
+// diagonal-quadratic or quartic objective, constraint blocks that are aligned lane groups) and the logical geometry is one
+// wave (128 < n <= 512).  Invisible in the results, so no policy: by batch alone -- 4 copies while they all stay resident
+// (3 workgroups of 4 x 11.5 KB of LDS per CU), 2 up to twice that, beyond it the chip is full of problems anyway.
+// FL_FORCE_REPLICAS in the environment overrides (tuning: tools/geometry_by_batch.py).
+#ifndef FL_REP4_MAX_BATCH
+#define FL_REP4_MAX_BATCH 1536
+#define FL_REP2_MAX_BATCH 4096
+#endif
+static int select_replicas(const GeoSel &g, int objective, int method, int n, int m, int batch)
+{
+    if (g.nw != 1 || (g.ept != 8 && g.ept != 4)) return 1;
+    if (objective != FL_OBJ_DIAGQUAD && objective != FL_OBJ_QUARTIC) return 1;
+    if (method != FL_SOLVER_LBFGS && method != FL_SOLVER_CG) return 1;
+    const int w = n / m;
+    if (w != 32 && w != 64 && w != 128) return 1; // (Solver::init: cshift)
+    if (const char *f = getenv("FL_FORCE_REPLICAS")) {
+        const int r = atoi(f);
+        return (r >= 2 && r <= 4) ? r : 1;
+    }
+    const long long scaled = (long long)batch * 256 / device_compute_units();
+    if (scaled <= FL_REP4_MAX_BATCH) return 4;
+    if (scaled <= FL_REP2_MAX_BATCH) return 2;
+    return 1;
+}
+
 #ifndef FL_ONLY_BENCH // the geometries are compiled in fl_solver_g*.hip
+extern template hipError_t launch_rep<1, 8>(int, int, int, const SolveArgs &, hipStream_t);
+extern template hipError_t launch_rep<1, 4>(int, int, int, const SolveArgs &, hipStream_t);
 extern template hipError_t launch_vec<1, 16>(int, int, const SolveArgs &, hipStream_t);
 extern template hipError_t launch_vec<2, 16>(int, int, const SolveArgs &, hipStream_t);
 extern template hipError_t launch_vec<4, 16>(int, int, const SolveArgs &, hipStream_t);
 extern template hipError_t launch_newton<2, 4>(int, int, const SolveArgs &, hipStream_t);
+extern template hipError_t launch_lat<2, 2>(int, int, int, const SolveArgs &, hipStream_t);
+extern template hipError_t launch_lat<2, 4>(int, int, int, const SolveArgs &, hipStream_t);
+extern template hipError_t launch_lat<4, 2>(int, int, int, const SolveArgs &, hipStream_t);
+extern template hipError_t launch_lat<4, 4>(int, int, int, const SolveArgs &, hipStream_t);
+extern template hipError_t launch_lat<8, 2>(int, int, int, const SolveArgs &, hipStream_t);
+extern template hipError_t launch_lat<8, 4>(int, int, int, const SolveArgs &, hipStream_t);
 extern template hipError_t launch_o<1, 2>(int, int, int, const SolveArgs &, hipStream_t);
 extern template hipError_t launch_o<1, 4>(int, int, int, const SolveArgs &, hipStream_t);
 extern template hipError_t launch_o<1, 8>(int, int, int, const SolveArgs &, hipStream_t);
@@ -129,7 +280,13 @@ static hipError_t launch(const GeoSel &g, int obj, int method, int aug, const So
     if (g.nw == 1 && g.ept == 16) return launch_vec<1, 16>(obj, method, A, st); // (select_fused_geometry: SD / CG, no constraints)
     if (g.nw == 2 && g.ept == 16) return launch_vec<2, 16>(obj, method, A, st);
     if (g.nw == 4 && g.ept == 16) return launch_vec<4, 16>(obj, method, A, st);
-    if (g.nw == 2 && g.ept == 4) return launch_newton<2, 4>(obj, aug, A, st);      // (select_fused_geometry: NewtonRaphson)
+    if (g.nw == 2 && g.ept == 4 && method == FL_SOLVER_NEWTON) return launch_newton<2, 4>(obj, aug, A, st); // (NewtonRaphson, 256 < n <= 512)
+    if (g.nw == 2 && g.ept == 2) return launch_lat<2, 2>(obj, method, aug, A, st); // the latency geometries (select_fused_geometry)
+    if (g.nw == 2 && g.ept == 4) return launch_lat<2, 4>(obj, method, aug, A, st);
+    if (g.nw == 4 && g.ept == 2) return launch_lat<4, 2>(obj, method, aug, A, st);
+    if (g.nw == 4 && g.ept == 4) return launch_lat<4, 4>(obj, method, aug, A, st);
+    if (g.nw == 8 && g.ept == 2) return launch_lat<8, 2>(obj, method, aug, A, st);
+    if (g.nw == 8 && g.ept == 4) return launch_lat<8, 4>(obj, method, aug, A, st);
     if (g.nw == 1 && g.ept == 2) return launch_o<1, 2>(obj, method, aug, A, st);
     if (g.nw == 1 && g.ept == 4) return launch_o<1, 4>(obj, method, aug, A, st);
     if (g.nw == 1 && g.ept == 8) return launch_o<1, 8>(obj, method, aug, A, st);
@@ -157,7 +314,7 @@ static int solve(int method, int objective, int batch, int n, double *x, const d
     if (opt->cg_method != FL_CG_DY && opt->cg_method != FL_CG_PR) return FL_ERR_INVALID_ARGUMENT;
     GeoSel g;
     bool big = false;
-    if (!select_fused_geometry(n, method, aug != nullptr, g)) {
+    if (!select_fused_geometry(n, method, aug != nullptr, batch, opt->geometry, g)) {
         // beyond the register path: SD / CG / L-BFGS continue with vectors in HBM; the dense solvers and the
         // augmented Lagrangian do not
         if (aug || method == FL_SOLVER_NEWTON) return FL_ERR_UNSUPPORTED_SIZE;
@@ -213,6 +370,15 @@ static int solve(int method, int objective, int batch, int n, double *x, const d
         }
         return launch_status(e);
     }
+#ifndef FL_ONLY_BENCH
+    if (aug) {
+        const int rep = select_replicas(g, objective, method, n, aug->m, batch);
+        if (rep > 1) {
+            const hipError_t er = g.ept == 8 ? launch_rep<1, 8>(rep, objective, method, A, st) : launch_rep<1, 4>(rep, objective, method, A, st);
+            return launch_status(er);
+        }
+    }
+#endif
     hipError_t e = launch(g, objective, method, aug != nullptr, A, st);
     return launch_status(e);
 }
@@ -249,6 +415,7 @@ void fl_default_options(fl_options *o, int solver)
     o->fused_f_fd = 0;
     o->clamp = 1;
     o->exact_step = 20; // NO.f90:652-653
+    o->geometry = FL_GEOMETRY_DEFAULT;
 }
 
 size_t fl_workspace_bytes_for(int solver, int batch, int n, const fl_options *opt)
@@ -301,10 +468,27 @@ int fl_reduction_geometry(int n, int *threads, int *ept)
 int fl_reduction_geometry_for(int solver, int n, int *threads, int *ept)
 {
     fl::GeoSel g;
-    if (!fl::select_fused_geometry(n, solver, false, g)) return fl_reduction_geometry(n, threads, ept);
+    if (!fl::select_throughput_geometry(n, solver, false, g)) return fl_reduction_geometry(n, threads, ept);
     if (threads) *threads = g.nw * 64;
     if (ept) *ept = g.ept;
     return FL_OK;
+}
+
+int fl_reduction_geometry_for_batch(int solver, int n, int batch, int constrained, int geometry, int *threads, int *ept)
+{
+    fl::GeoSel g;
+    if (batch <= 0) return FL_ERR_INVALID_ARGUMENT;
+    if (!fl::select_fused_geometry(n, solver, constrained != 0, batch, geometry, g)) return fl_reduction_geometry(n, threads, ept);
+    if (threads) *threads = g.nw * 64;
+    if (ept) *ept = g.ept;
+    return FL_OK;
+}
+
+int fl_set_geometry_policy(int policy)
+{
+    const int old = fl::process_geometry_policy();
+    if (policy >= FL_GEOMETRY_THROUGHPUT && policy <= FL_GEOMETRY_AUTO) fl::g_geometry_policy.store(policy, std::memory_order_relaxed);
+    return old;
 }
 
 size_t fl_workspace_bytes(int solver, int batch, int n, int memory)

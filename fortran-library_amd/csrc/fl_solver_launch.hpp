@@ -20,6 +20,9 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> constexpr int min_waves
     return FL_MIN_WPE;
 #else
     // (the quartic / Rosenbrock instances would spill 10-14 VGPRs under the cap: left alone)
+    // the latency geometries (several waves x at most 4 elements per thread: launch_lat below) run on an under-filled chip by
+    // definition -- one or two of their waves per SIMD -- so no occupancy cap is worth a spilled register there
+    if (NW >= 2 && EPT <= 4) return 1;
     if (AUG && EPT == 4 && NW <= 2 && tuned_like<OBJ>() == FL_OBJ_DIAGQUAD && (METHOD == FL_SOLVER_LBFGS || METHOD == FL_SOLVER_CG)) return 4;
     if (FL_AUG_LEAN18 && AUG && EPT == 8 && NW == 1 && tuned_like<OBJ>() == FL_OBJ_DIAGQUAD && (METHOD == FL_SOLVER_LBFGS || METHOD == FL_SOLVER_CG)) return FL_AUG18_WPE; // Solver::AUG_LEAN18 (4 waves: 80-100 spills)
     // SD / CG on them at 8 elements per thread, x0 in LDS (Solver::X0_LDS)
@@ -45,6 +48,14 @@ void fl_solve_kernel(SolveArgs A)
     double fv = 0.0, pv = 0.0, gg = 0.0;
     bool have_g = false; // augmented Lagrangian: objective-only trials skip the gradient until it is asked for
     constexpr int SK = S::SPEC_K;
+#ifdef FL_PHASE_TIMERS // tuning builds only (tools/phase_timers.py): where a problem's wall time goes, in 10 ns ticks, to A.user
+    long long tm[6] = {0, 0, 0, 0, 0, 0}, tc[6] = {0, 0, 0, 0, 0, 0};
+#define FL_T0 const long long t0_ = wall_clock64()
+#define FL_T1(i_) do { tm[i_] += wall_clock64() - t0_; ++tc[i_]; } while (0)
+#else
+#define FL_T0
+#define FL_T1(i_)
+#endif
     while (rq) {
         // which evaluation the request needs (each form is inlined once)
         bool f_only = false, full = false;
@@ -54,7 +65,9 @@ void fl_solve_kernel(SolveArgs A)
             bool forwarded = false;
             if constexpr (SK > 1) { // an objective-only shrinking loop of the line search: run it as a tight loop to its exit
                 if (f_only && s.spec_shrinking()) {
+                    FL_T0;
                     fv = s.template fast_forward<SK>(); // (leaves x at the exit trial's point)
+                    FL_T1(0);
                     have_g = false;
                     f_only = false;
                     forwarded = true;
@@ -62,7 +75,9 @@ void fl_solve_kernel(SolveArgs A)
             }
             if constexpr (S::GROW_K > 1) { // the growing loop of StrongWolfe (f and f' per trial): GROW_K trials per pass
                 if (full && !(rq & FL_REQ_NOMOVE) && s.grow_loop_pending()) {
+                    FL_T0;
                     s.template fast_forward_grow<S::GROW_K>(fv, pv); // (leaves x, g at the exit trial's point)
+                    FL_T1(1);
                     have_g = true;
                     full = false;
                     forwarded = true;
@@ -73,16 +88,152 @@ void fl_solve_kernel(SolveArgs A)
             full = true;
         }
         if (AUG && f_only) {
+            FL_T0;
             s.template evaluate<false>(fv, pv, gg);
             have_g = false;
+            FL_T1(2);
         }
         if (full) {
+            FL_T0;
             s.template evaluate<true>(fv, pv, gg);
             have_g = true;
+            FL_T1(3);
         }
-        rq = s.advance(fv, pv, gg);
+        {
+            FL_T0;
+#ifdef FL_PHASE_TIMERS
+            const int it0 = s.iters + s.inner_iters_total;
+#endif
+            rq = s.advance(fv, pv, gg);
+#ifdef FL_PHASE_TIMERS
+            if (s.iters + s.inner_iters_total != it0) FL_T1(5); // a line search ended: convergence tests + the new direction
+            else FL_T1(4);
+#endif
+        }
     }
     s.finish();
+#ifdef FL_PHASE_TIMERS
+    if (A.user && threadIdx.x == 0) {
+        long long *o = (long long *)A.user + (size_t)blockIdx.x * 12;
+        for (int i = 0; i < 6; ++i) { o[i] = tm[i]; o[6 + i] = tc[i]; }
+    }
+#endif
+}
+
+// A master wave and REP - 1 helper waves per problem (Solver::fast_forward_wide_cs): the master runs the machine exactly as
+// fl_solve_kernel<1, EPT, ...> does, the helpers take their share of the objective-only shrink loop of the line search --
+// trial-parallel -- and otherwise wait at the workgroup barrier.  For the augmented-Lagrangian kernels whose geometry is one
+// wave (n <= 512), picked by the host for batches that under-fill the chip.  Results are bit for bit fl_solve_kernel's.
+// Barrier protocol: a helper sits in `for (;;) { barrier; read cmd; ... }`, so EVERY barrier the master executes outside the
+// shared loop is matched by one turn of that loop; cmd (LDS, written by the master's lane 0 before the barrier that publishes
+// it) = 1: a shrink loop starts behind this barrier -- both sides then execute the same passes, the same exits, hence the
+// same barriers -- = 2: the problem is finished (a terminated wave no longer counts at s_barrier), = 0: nothing.
+#ifndef FL_REP_WPE
+#define FL_REP_WPE 3
+#endif
+// three waves per SIMD where the unhelped kernel runs three as well (Solver::AUG_LEAN18: BASELINE config 5's kernel; 3 helped
+// problems of 4 waves, or 4 of 3, per CU); 7 VGPRs go to scratch for it, none of them inside the shared loop.  The others as
+// the allocator likes (the quartic's machine at one wave x 8 would spill 40-64)
+template <int NW, int EPT, int OBJ, int METHOD> constexpr int rep_waves_per_simd()
+{
+    return (FL_AUG_LEAN18 && NW == 1 && EPT == 8 && tuned_like<OBJ>() == FL_OBJ_DIAGQUAD) ? FL_REP_WPE : 1;
+}
+template <int REP, int NW, int EPT, int OBJ, int METHOD, int AUG>
+__global__ __launch_bounds__(REP * NW * 64) __attribute__((amdgpu_waves_per_eu(rep_waves_per_simd<NW, EPT, OBJ, METHOD>())))
+void fl_solve_rep_kernel(SolveArgs A)
+{
+    using S = Solver<NW, EPT, OBJ, METHOD, AUG, 0>;
+    static_assert(NW == 1 && AUG && S::SPEC_K > 1, "helpers share out the speculative objective-only trials of a one-wave machine");
+    static_assert(S::Obj::LDS_DOUBLES == 0, "the helpers keep no LDS image of the objective");
+    constexpr int SK = S::SPEC_K;
+    constexpr int LT = (S::LDS_TOTAL + 1) & ~1; // the master's LDS
+    constexpr int HL = (S::L_XS + 1) & ~1;      // a helper's: the machine's small arrays (lambda, c(x) buffers of its trials)
+    constexpr int PUB = (S::PUB_DOUBLES + 2 + 1) & ~1; // what the master publishes per loop, then the command word
+    __shared__ __attribute__((aligned(16))) double lds[LT + (REP - 1) * HL + PUB + 4 * SK * REP + REP + 2];
+    const int rep = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    double *pub = lds + LT + (REP - 1) * HL, *xch = pub + PUB;
+    volatile int *cmd = reinterpret_cast<volatile int *>(pub + S::PUB_DOUBLES);
+    const bool lane0 = (threadIdx.x & 63) == 0, master = rep == 0;
+    // ONE machine object and ONE copy of the shared loop for both roles (two objects in two branches made the register
+    // allocator serve both paths at once: 199 VGPRs, or 64 spilled under the occupancy cap)
+    S s(A, master ? lds : lds + LT + (rep - 1) * HL);
+    if (master && lane0) *cmd = 0;
+    s.init();
+    int rq = master ? s.start() : 0;
+    double fv = 0.0, pv = 0.0, gg = 0.0;
+    bool have_g = false;
+    for (;;) { // one turn = one request of the master's machine (one call site of advance(): it is inlined once)
+        int c = 0; // 1: a shrink loop is shared out behind the next barrier, 2: the problem is finished
+        bool f_only = false, full = false;
+        if (master) {
+            if (!rq) {
+                c = 2;
+            } else if (!(rq & FL_REQ_SAME)) {
+                if (!(rq & FL_REQ_G)) f_only = true;
+                else full = true;
+                if (f_only && s.spec_shrinking()) c = 1;
+                else if (!(rq & FL_REQ_NOMOVE)) s.move(s.request_point());
+            } else if ((rq & FL_REQ_G) && !have_g) {
+                full = true;
+            }
+            if (c) {
+                if (c == 1) s.publish_search(pub);
+                if (lane0) *cmd = c;
+                __syncthreads();
+            }
+        } else {
+            do { // every barrier the master executes on its way is matched by one turn
+                __syncthreads();
+                c = __builtin_amdgcn_readfirstlane(*cmd);
+            } while (c == 0);
+            if (c == 1) s.helper_take(pub);
+        }
+        if (c == 2) break;
+        if (c == 1) {
+            const double fx = s.template fast_forward_wide<SK, REP>(xch, rep, lds + S::L_X0, master);
+            if (master) {
+                if (lane0) *cmd = 0; // (behind the loop's last barrier; the helpers read it behind the master's next one)
+                fv = fx;
+                have_g = false;
+                f_only = false;
+            }
+        }
+        if (master) {
+            if (f_only) {
+                s.template evaluate<false>(fv, pv, gg);
+                have_g = false;
+            }
+            if (full) {
+                s.template evaluate<true>(fv, pv, gg);
+                have_g = true;
+            }
+            rq = s.advance(fv, pv, gg);
+        }
+    }
+    if (master) s.finish();
+}
+template <int REP, int NW, int EPT, int OBJ, int METHOD>
+static hipError_t launch_rep_k(const SolveArgs &A, hipStream_t st)
+{
+    hipLaunchKernelGGL((fl_solve_rep_kernel<REP, NW, EPT, OBJ, METHOD, 1>), dim3(A.batch), dim3(REP * NW * 64), 0, st, A);
+    return hipGetLastError();
+}
+// (fl_solver_g*r.hip) objective: FL_OBJ_DIAGQUAD | FL_OBJ_QUARTIC, method: FL_SOLVER_LBFGS | FL_SOLVER_CG
+template <int NW, int EPT> hipError_t launch_rep(int rep, int obj, int method, const SolveArgs &A, hipStream_t st)
+{
+#define FL_REP(R_, O_)                                                                                     \
+    return method == FL_SOLVER_CG ? launch_rep_k<R_, NW, EPT, O_, FL_SOLVER_CG>(A, st) : launch_rep_k<R_, NW, EPT, O_, FL_SOLVER_LBFGS>(A, st)
+    if (rep == 2) {
+        if (obj == FL_OBJ_QUARTIC) FL_REP(2, FL_OBJ_QUARTIC);
+        FL_REP(2, FL_OBJ_DIAGQUAD);
+    }
+    if (rep == 3) {
+        if (obj == FL_OBJ_QUARTIC) FL_REP(3, FL_OBJ_QUARTIC);
+        FL_REP(3, FL_OBJ_DIAGQUAD);
+    }
+    if (obj == FL_OBJ_QUARTIC) FL_REP(4, FL_OBJ_QUARTIC);
+    FL_REP(4, FL_OBJ_DIAGQUAD);
+#undef FL_REP
 }
 
 // the reference's optional arguments -> the kernel's arguments (defaults and clamps of NO.f90:419-434); shared by the
@@ -127,6 +278,9 @@ static inline void fill_solve_args(SolveArgs &A, int method, int batch, int n, d
     A.outer = nullptr;
     A.cnorm2 = nullptr;
     A.user = nullptr;
+#ifdef FL_PHASE_TIMERS
+    if (const char *e = getenv("FL_PHASE_BUFFER")) A.user = (const void *)strtoull(e, nullptr, 16); // [batch][12] int64, device
+#endif
 }
 
 template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = 0>
@@ -179,6 +333,31 @@ template <int NW, int EPT> hipError_t launch_vec(int obj, int method, const Solv
     case FL_OBJ_QUARTIC: return launch_vec_m<NW, EPT, FL_OBJ_QUARTIC>(method, A, st);
     case FL_OBJ_ROSENBROCK: return launch_vec_m<NW, EPT, FL_OBJ_ROSENBROCK>(method, A, st);
     default: return launch_vec_m<NW, EPT, FL_OBJ_DIAGQUAD>(method, A, st);
+    }
+}
+
+// LATENCY geometries (fl_solver_g*l.hip): the same solvers on MORE waves x FEWER elements per thread than the throughput
+// geometry of their n, for batches that leave the chip under-filled (a GPU's share of BASELINE config 5 on eight GPUs:
+// 1024 problems on 256 CUs) -- there a problem's wall time is the latency of its trial chain, and the element-wise part of a
+// trial shrinks with the elements per thread.  The vector solvers only (SD, CG, L-BFGS; the augmented Lagrangian around
+// CG / L-BFGS): the dense ones are bound by their passes over H.  Same padded row length threads*ept as the throughput
+// geometry, so workspaces do not change; the summation order does (the oracle replays any threads x ept).
+template <int NW, int EPT, int OBJ> static hipError_t launch_lat_m(int method, int aug, const SolveArgs &A, hipStream_t st)
+{
+    if (aug) {
+        if (method == FL_SOLVER_CG) return launch_k<NW, EPT, OBJ, FL_SOLVER_CG, 1>(A, st);
+        return launch_k<NW, EPT, OBJ, FL_SOLVER_LBFGS, 1>(A, st);
+    }
+    if (method == FL_SOLVER_SD) return launch_k<NW, EPT, OBJ, FL_SOLVER_SD, 0>(A, st);
+    if (method == FL_SOLVER_CG) return launch_k<NW, EPT, OBJ, FL_SOLVER_CG, 0>(A, st);
+    return launch_k<NW, EPT, OBJ, FL_SOLVER_LBFGS, 0>(A, st);
+}
+template <int NW, int EPT> hipError_t launch_lat(int obj, int method, int aug, const SolveArgs &A, hipStream_t st)
+{
+    switch (obj) {
+    case FL_OBJ_QUARTIC: return launch_lat_m<NW, EPT, FL_OBJ_QUARTIC>(method, aug, A, st);
+    case FL_OBJ_ROSENBROCK: return launch_lat_m<NW, EPT, FL_OBJ_ROSENBROCK>(method, aug, A, st);
+    default: return launch_lat_m<NW, EPT, FL_OBJ_DIAGQUAD>(method, aug, A, st);
     }
 }
 

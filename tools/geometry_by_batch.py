@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Wall time of the fused kernels by batch size and reduction geometry (MI355X, one GPU): the table behind the break-even
+batches of FL_GEOMETRY_AUTO (csrc/fl_solver_kernels.hip: latency_candidates) -> profiles/r04/geometry_by_batch.txt.
+
+For every workload and batch the same problems (the first `batch` of the benched family) are solved under the throughput
+geometry of n and under each latency candidate (FL_FORCE_GEOMETRY, read by the library per call), three launches each,
+the minimum kept (HIP events on the launch stream).  Iteration totals are printed too: geometries differ in summation
+order, so their paths differ in the last bits and a handful of iterations.
+usage: python tools/geometry_by_batch.py [c5 headline c3 c2 lbfgs512 cg512 lbfgs2048] [--batches 256,1024,2048,4096,8192]
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "fortran-library_amd"))
+sys.path.insert(0, ROOT)
+import torch
+import FortranLibrary.NonlinearOptimization as NLO
+from bench import SEED
+
+dev = torch.device("cuda:0")
+
+
+def quad(B, n, klo, khi):
+    d = torch.empty(B, n, dtype=torch.float64, device=dev)
+    b = torch.empty(B, n, dtype=torch.float64, device=dev)
+    NLO.synth_diag_spectrum(SEED, d, klo, khi)
+    NLO.synth_uniform(SEED, b, -1.0, 1.0)
+    return d, b
+
+
+def timed(fn, reps=3):
+    fn()
+    torch.cuda.synchronize()
+    best, out = None, None
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        best = ms if best is None else min(best, ms)
+    return out, best
+
+
+def workload(name, B):
+    """-> (run(), candidates) for the first B problems of the family"""
+    if name == "c5":
+        n, M, m = 512, 8, 10
+        d, b = quad(B, n, 2.0, 10.0)
+        x0 = torch.empty(B, n, dtype=torch.float64, device=dev)
+        NLO.synth_uniform(SEED + 7, x0, 0.05, 0.15)
+        x = torch.empty_like(x0)
+        ws = NLO.workspace(B, n, m, dev)
+
+        def run():
+            x.copy_(x0)
+            return NLO.AugmentedLagrangian(NLO.DIAGQUAD, x, M, d, b, UnconstrainedSolver="LBFGS", workspace_=ws, Precision=1e-10, Memory=m)
+        return run, ["1x8", "2x4", "4x2", "1x8r2", "1x8r3", "1x8r4"]
+    if name in ("headline", "lbfgs512", "lbfgs256", "lbfgs2048"):
+        n = {"headline": 1024, "lbfgs512": 512, "lbfgs256": 256, "lbfgs2048": 2048}[name]
+        d, b = quad(B, n, 10.0, 1000.0)
+        x = torch.zeros(B, n, dtype=torch.float64, device=dev)
+        ws = NLO.workspace(B, n, 10, dev)
+
+        def run():
+            x.zero_()
+            return NLO.LBFGS(NLO.DIAGQUAD, x, d, b, workspace_=ws, Precision=1e-6, MaxIteration=3000)
+        return run, {1024: ["2x8", "4x4", "8x2"], 512: ["1x8", "2x4", "4x2"], 256: ["1x4", "2x2"], 2048: ["4x8", "8x4"]}[n]
+    if name in ("c3", "cg512"):
+        n = 1024 if name == "c3" else 512
+        d, b = quad(B, n, 10.0, 1000.0)
+        x = torch.zeros(B, n, dtype=torch.float64, device=dev)
+
+        def run():
+            x.zero_()
+            return NLO.ConjugateGradient(NLO.DIAGQUAD, x, d, b, Precision=1e-6, MaxIteration=3000)
+        return run, (["1x16", "4x4", "8x2"] if n == 1024 else ["1x8", "2x4", "4x2"])
+    if name == "c2":
+        n, m = 256, 10
+        x0 = torch.empty(B, n, dtype=torch.float64, device=dev)
+        NLO.synth_uniform(SEED, x0, 0.9, 1.1)
+        ws = NLO.workspace(B, n, m, dev)
+        x = torch.empty_like(x0)
+
+        def run():
+            x.copy_(x0)
+            return NLO.LBFGS(NLO.ROSENBROCK, x, workspace_=ws, Precision=1e-10, MaxIteration=3000, Memory=m)
+        return run, ["1x4", "2x2"]
+    raise SystemExit("unknown workload " + name)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("workloads", nargs="*", default=["c5", "headline"])
+    ap.add_argument("--batches", default="256,1024,2048,4096,8192")
+    args = ap.parse_args()
+    for name in args.workloads:
+        for B in [int(v) for v in args.batches.split(",")]:
+            run, cands = workload(name, B)
+            row = {"workload": name, "batch": B}
+            for i, c in enumerate(cands):
+                # (the first one is the throughput geometry: not a latency candidate -> ignored; "r2" / "r4": replicated groups)
+                os.environ["FL_FORCE_GEOMETRY"] = c.split("r")[0]
+                os.environ["FL_FORCE_REPLICAS"] = c.split("r")[1] if "r" in c else "1"
+                out, ms = timed(run)
+                row[c] = round(ms, 3)
+                row[c + "_iters"] = int(out["iters"].to(torch.int64).sum())
+            os.environ.pop("FL_FORCE_GEOMETRY", None)
+            os.environ.pop("FL_FORCE_REPLICAS", None)
+            print(json.dumps(row), flush=True)
+            del run
+            torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
