@@ -23,11 +23,7 @@ class Options(C.Structure):
     _fields_ = [("strong", C.c_int32), ("max_iteration", C.c_int32), ("precision", C.c_double),
                 ("min_step_length", C.c_double), ("wolfe_c1", C.c_double), ("wolfe_c2", C.c_double),
                 ("increment", C.c_double), ("memory", C.c_int32), ("cg_method", C.c_int32),
-                ("fused_f_fd", C.c_int32), ("clamp", C.c_int32), ("exact_step", C.c_int32), ("geometry", C.c_int32)]
-
-
-GEOMETRY_DEFAULT, GEOMETRY_THROUGHPUT, GEOMETRY_LATENCY, GEOMETRY_AUTO = 0, 1, 2, 3
-_GEOMETRY = {None: 0, "default": 0, "throughput": 1, "latency": 2, "auto": 3, 0: 0, 1: 1, 2: 2, 3: 3}
+                ("fused_f_fd", C.c_int32), ("clamp", C.c_int32), ("exact_step", C.c_int32)]
 
 
 _vp, _dp, _ip = C.c_void_p, C.c_void_p, C.c_void_p
@@ -36,8 +32,6 @@ FL.fl_default_options.argtypes = [C.POINTER(Options), C.c_int]
 FL.fl_default_options.restype = None
 FL.fl_reduction_geometry.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
 FL.fl_reduction_geometry_for.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
-FL.fl_reduction_geometry_for_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
-FL.fl_set_geometry_policy.argtypes = [C.c_int]
 FL.fl_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
 FL.fl_workspace_bytes.restype = C.c_size_t
 FL.fl_lbfgs_batched.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.POINTER(Options), _vp, C.c_size_t, _dp,
@@ -68,8 +62,7 @@ def _check(rc, what):
 def default_options(solver, **kw):
     """Reference defaults (NO.f90:73-86, 419-434), overridden by reference-named keywords:
     Strong, MaxIteration, Precision, MinStepLength, WolfeConst1, WolfeConst2, Increment, Memory,
-    Method ('DY'|'PR'), f_fd (bool: act as if f_fd was passed), clamp; Geometry ('throughput' | 'latency' | 'auto' |
-    None = the process policy: which reduction geometry the fused kernels take for the batch, fl_options.geometry)."""
+    Method ('DY'|'PR'), f_fd (bool: act as if f_fd was passed), clamp."""
     o = Options()
     FL.fl_default_options(C.byref(o), solver)
     ren = {"Strong": "strong", "MaxIteration": "max_iteration", "Precision": "precision",
@@ -83,10 +76,6 @@ def default_options(solver, **kw):
             if v not in ("DY", "PR"):  # reference: "Program abort: unsupported conjugate gradient method" (NO.f90:345)
                 raise ValueError("unsupported conjugate gradient method " + str(v))
             o.cg_method = 0 if v == "DY" else 1
-        elif k == "Geometry":
-            if v not in _GEOMETRY:
-                raise ValueError("unknown geometry policy " + str(v))
-            o.geometry = _GEOMETRY[v]
         elif k in ren:
             setattr(o, ren[k], int(v) if isinstance(v, bool) else v)
         else:
@@ -94,24 +83,11 @@ def default_options(solver, **kw):
     return o
 
 
-def set_geometry_policy(policy):
-    """process-wide geometry policy of the fused kernels ('throughput' | 'latency' | 'auto'); returns the previous one"""
-    names = {1: "throughput", 2: "latency", 3: "auto"}
-    if policy not in _GEOMETRY or _GEOMETRY[policy] == 0:
-        raise ValueError("unknown geometry policy " + str(policy))
-    return names[FL.fl_set_geometry_policy(_GEOMETRY[policy])]
-
-
-def reduction_geometry(n, solver=None, batch=None, constrained=False, Geometry=None):
+def reduction_geometry(n, solver=None):
     """(threads, elements per thread) of the kernels' fixed summation order for dimension n; with `solver` (SD | CG |
-    LBFGS_ | BFGS_ | 4): of that solver's fused kernel (fl_reduction_geometry_for); with `batch` too: of the fused kernel for
-    that many problems on this device under the geometry policy (fl_reduction_geometry_for_batch; constrained = inside the
-    augmented Lagrangian) -- what to hand to the oracle to replay a batched solve bit for bit"""
+    LBFGS_ | BFGS_ | 4): of that solver's fused kernel (fl_reduction_geometry_for)"""
     t, e = C.c_int(), C.c_int()
-    if batch is not None:
-        _check(FL.fl_reduction_geometry_for_batch(int(LBFGS_ if solver is None else solver), n, int(batch), int(bool(constrained)),
-                                                  _GEOMETRY[Geometry], C.byref(t), C.byref(e)), "fl_reduction_geometry_for_batch")
-    elif solver is None:
+    if solver is None:
         _check(FL.fl_reduction_geometry(n, C.byref(t), C.byref(e)), "fl_reduction_geometry")
     else:
         _check(FL.fl_reduction_geometry_for(int(solver), n, C.byref(t), C.byref(e)), "fl_reduction_geometry_for")

@@ -13,25 +13,9 @@
 #include "fl_solver_launch.hpp"
 #include "fl_big.hpp"
 #include <atomic>
-#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
-// break-even batches of the latency geometries (problems per 256 CUs; profiles/r04/geometry_by_batch.txt)
-#ifndef FL_LAT_256_A
-#define FL_LAT_256_A 2048
-#define FL_LAT_512_A 1024
-#define FL_LAT_512_B 3072
-#define FL_LAT_1024_A 512
-#define FL_LAT_1024_B 2048
-#define FL_LAT_2048_A 1024
-#define FL_LAT_AUG_256_A 2048
-#define FL_LAT_AUG_512_A 1024
-#define FL_LAT_AUG_512_B 3072
-#define FL_LAT_AUG_1024_A 512
-#define FL_LAT_AUG_1024_B 2048
-#define FL_LAT_AUG_2048_A 1024
-#endif
 
 
 namespace fl {
@@ -115,7 +99,7 @@ static bool select_geometry(int n, GeoSel &g)
 // every reduction stays inside the wave and the reduction / line-search scalar work is done once instead of twice
 // (C3: 65.4 -> 54.3 ms).  Same padded length threads*ept as the layout geometry of n; L-BFGS (row buffers, ring pairs)
 // and the dense solvers keep 2 x 8, and so do the reverse-communication kernels.
-static bool select_throughput_geometry(int n, int method, bool aug, GeoSel &g)
+static bool select_fused_geometry(int n, int method, bool aug, GeoSel &g)
 {
     if (!select_geometry(n, g)) return false;
     if (!aug && (method == FL_SOLVER_SD || method == FL_SOLVER_CG) && n > 512) g = {g.nw / 2, 16}; // 1 x 16, 2 x 16, 4 x 16
@@ -124,34 +108,18 @@ static bool select_throughput_geometry(int n, int method, bool aug, GeoSel &g)
     if (method == FL_SOLVER_NEWTON && n > 256 && n <= 512) g = {2, 4};
     return true;
 }
-
-// ---- geometry by BATCH (round 4).  The throughput geometries above are tuned for a chip full of problems.  A batch that
-// leaves it under-filled -- one GPU's share of BASELINE config 5 on eight GPUs is 1024 problems for 256 CUs -- is bound by
-// the latency of one problem's trial chain instead, and there more waves x fewer elements per thread win: the element-wise
-// part of every trial shrinks with the elements per thread while the reductions grow only by the cross-wave step.
-// Policy: fl_options.geometry, else the process policy (fl_set_geometry_policy / FL_GEOMETRY in the environment; default
-// FL_GEOMETRY_AUTO).  AUTO takes a latency geometry while batch <= its measured break-even (a table per n range, in
-// problems per 256 CUs, scaled by the device's CU count; profiles/r04/geometry_by_batch.txt).
-static std::atomic<int> g_geometry_policy{-1};
-static int process_geometry_policy()
-{
-    int p = g_geometry_policy.load(std::memory_order_relaxed);
-    if (p >= 0) return p;
-    p = FL_GEOMETRY_AUTO;
-    if (const char *e = getenv("FL_GEOMETRY")) {
-        if (!strcmp(e, "throughput")) p = FL_GEOMETRY_THROUGHPUT;
-        else if (!strcmp(e, "latency")) p = FL_GEOMETRY_LATENCY;
-        else if (!strcmp(e, "auto")) p = FL_GEOMETRY_AUTO;
-    }
-    g_geometry_policy.store(p, std::memory_order_relaxed);
-    return p;
-}
+// The geometry is a function of n (and the solver) alone -- NOT of the batch size: round 4 measured "latency" geometries
+// (2 x 2, 2 x 4, 4 x 2, 4 x 4, 8 x 2, 8 x 4: more waves x fewer elements per thread) for batches that under-fill the chip, all
+// bit-exact against the oracle, and none pays: the unconstrained solvers are fastest in their throughput geometry at EVERY
+// batch from 256 to 8192 (one exception, 8 %: L-BFGS n = 1024 at 256 problems on 4 x 4), and BASELINE config 5's shares are
+// served better by helper waves (below), which leave the summation order -- hence every bit of the result -- alone
+// (profiles/r04/geometry_by_batch.txt; the kernels are in the history at commit ca4f3a1).
 static int device_compute_units()
 {
     static std::atomic<int> cus{0};
     int c = cus.load(std::memory_order_relaxed);
     if (c > 0) return c;
-    c = 256; // MI355X; also what the geometry queries answer with on a machine without a device
+    c = 256;
     int dev = 0;
     hipDeviceProp_t pr;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
@@ -160,76 +128,20 @@ static int device_compute_units()
     cus.store(c, std::memory_order_relaxed);
     return c;
 }
-struct LatencyChoice {
-    int nw, ept;
-    int max_batch; // per 256 CUs: AUTO takes this geometry while the batch is at most this
-};
-// candidates of an n range, most waves first (FL_GEOMETRY_LATENCY takes the first)
-static int latency_candidates(int n, int method, bool aug, const LatencyChoice **out)
-{
-    // measured on MI355X (profiles/r04/geometry_by_batch.txt); unconstrained SD / CG / L-BFGS and the augmented Lagrangian
-    // around CG / L-BFGS have tables of their own: the constrained trial chain is longer, so its break-even lies higher
-    static const LatencyChoice c256[] = {{2, 2, FL_LAT_256_A}};
-    static const LatencyChoice c512[] = {{4, 2, FL_LAT_512_A}, {2, 4, FL_LAT_512_B}};
-    static const LatencyChoice c1024[] = {{8, 2, FL_LAT_1024_A}, {4, 4, FL_LAT_1024_B}};
-    static const LatencyChoice c2048[] = {{8, 4, FL_LAT_2048_A}};
-    static const LatencyChoice a256[] = {{2, 2, FL_LAT_AUG_256_A}};
-    static const LatencyChoice a512[] = {{4, 2, FL_LAT_AUG_512_A}, {2, 4, FL_LAT_AUG_512_B}};
-    static const LatencyChoice a1024[] = {{8, 2, FL_LAT_AUG_1024_A}, {4, 4, FL_LAT_AUG_1024_B}};
-    static const LatencyChoice a2048[] = {{8, 4, FL_LAT_AUG_2048_A}};
-    if (method != FL_SOLVER_SD && method != FL_SOLVER_CG && method != FL_SOLVER_LBFGS) return 0;
-    if (aug && method == FL_SOLVER_SD) return 0;
-    if (n <= 128 || n > 2048) return 0;
-#define FL_PICK(T_) do { *out = T_; return (int)(sizeof(T_) / sizeof(T_[0])); } while (0)
-    if (n <= 256) { if (aug) FL_PICK(a256); else FL_PICK(c256); }
-    if (n <= 512) { if (aug) FL_PICK(a512); else FL_PICK(c512); }
-    if (n <= 1024) { if (aug) FL_PICK(a1024); else FL_PICK(c1024); }
-    if (aug) FL_PICK(a2048); else FL_PICK(c2048);
-#undef FL_PICK
-}
-static bool select_fused_geometry(int n, int method, bool aug, int batch, int geometry, GeoSel &g)
-{
-    if (!select_throughput_geometry(n, method, aug, g)) return false;
-#ifdef FL_FORCE_GEO_N
-    return true;
-#endif
-    int policy = (geometry >= FL_GEOMETRY_THROUGHPUT && geometry <= FL_GEOMETRY_AUTO) ? geometry : process_geometry_policy();
-    const LatencyChoice *c = nullptr;
-    const int nc = latency_candidates(n, method, aug, &c);
-    if (nc == 0) return true;
-    if (const char *f = getenv("FL_FORCE_GEOMETRY")) { // tuning knob (tools/geometry_by_batch.py): "4x2" = that candidate of the range
-        int fw = 0, fe = 0;
-        if (sscanf(f, "%dx%d", &fw, &fe) == 2)
-            for (int i = 0; i < nc; ++i)
-                if (c[i].nw == fw && c[i].ept == fe) {
-                    g = {fw, fe};
-                    return true;
-                }
-        return true; // (anything else: the throughput geometry)
-    }
-    if (policy == FL_GEOMETRY_THROUGHPUT) return true;
-    if (policy == FL_GEOMETRY_LATENCY) {
-        g = {c[0].nw, c[0].ept};
-        return true;
-    }
-    const long long scaled = (long long)batch * 256 / device_compute_units(); // the batch as a 256-CU device would see it
-    for (int i = 0; i < nc; ++i)
-        if (scaled <= c[i].max_batch) {
-            g = {c[i].nw, c[i].ept};
-            return true;
-        }
-    return true;
-}
 
-// Replicated groups (fl_solve_rep_kernel): how many complete copies of the machine share a problem's objective-only shrink
-// loop.  Only where that loop runs as a tight loop at all (Solver::spec_shrinking: augmented Lagrangian around L-BFGS / CG,
-// diagonal-quadratic or quartic objective, constraint blocks that are aligned lane groups) and the logical geometry is one
-// wave (128 < n <= 512).  Invisible in the results, so no policy: by batch alone -- 4 copies while they all stay resident
-// (3 workgroups of 4 x 11.5 KB of LDS per CU), 2 up to twice that, beyond it the chip is full of problems anyway.
+// Helper waves (fl_solve_rep_kernel): how many waves share a problem's objective-only shrink loop by trial -- the master that
+// runs the machine plus R - 1 helpers.  Only where that loop runs as a tight loop at all (Solver::spec_shrinking: augmented
+// Lagrangian around L-BFGS / CG, diagonal-quadratic or quartic objective, constraint blocks that are aligned lane groups) and
+// the geometry is one wave (128 < n <= 512).  Invisible in the results, so there is no option for it: by batch alone.
+// Measured on BASELINE config 5's family (ms; profiles/r04/geometry_by_batch.txt):
+//   batch      256   512  1024  1280  1536  2048  3072  4096  8192
+//   R = 1     63.2  64.1  72.5  73.4  73.2  75.7  80.6 103.5 140.9
+//   R = 2     42.0  50.5  54.7  55.5  60.5  63.3  85.9 104.2 178.9
+//   R = 4     29.9  35.9  50.4  54.8  68.1  74.0 108.1 137.5 252.8
 // FL_FORCE_REPLICAS in the environment overrides (tuning: tools/geometry_by_batch.py).
 #ifndef FL_REP4_MAX_BATCH
-#define FL_REP4_MAX_BATCH 1536
-#define FL_REP2_MAX_BATCH 4096
+#define FL_REP4_MAX_BATCH 1280 // (problems per 256 CUs)
+#define FL_REP2_MAX_BATCH 2560
 #endif
 static int select_replicas(const GeoSel &g, int objective, int method, int n, int m, int batch)
 {
@@ -240,7 +152,7 @@ static int select_replicas(const GeoSel &g, int objective, int method, int n, in
     if (w != 32 && w != 64 && w != 128) return 1; // (Solver::init: cshift)
     if (const char *f = getenv("FL_FORCE_REPLICAS")) {
         const int r = atoi(f);
-        return (r >= 2 && r <= 4) ? r : 1;
+        return (r == 2 || r == 4) ? r : 1;
     }
     const long long scaled = (long long)batch * 256 / device_compute_units();
     if (scaled <= FL_REP4_MAX_BATCH) return 4;
@@ -255,12 +167,6 @@ extern template hipError_t launch_vec<1, 16>(int, int, const SolveArgs &, hipStr
 extern template hipError_t launch_vec<2, 16>(int, int, const SolveArgs &, hipStream_t);
 extern template hipError_t launch_vec<4, 16>(int, int, const SolveArgs &, hipStream_t);
 extern template hipError_t launch_newton<2, 4>(int, int, const SolveArgs &, hipStream_t);
-extern template hipError_t launch_lat<2, 2>(int, int, int, const SolveArgs &, hipStream_t);
-extern template hipError_t launch_lat<2, 4>(int, int, int, const SolveArgs &, hipStream_t);
-extern template hipError_t launch_lat<4, 2>(int, int, int, const SolveArgs &, hipStream_t);
-extern template hipError_t launch_lat<4, 4>(int, int, int, const SolveArgs &, hipStream_t);
-extern template hipError_t launch_lat<8, 2>(int, int, int, const SolveArgs &, hipStream_t);
-extern template hipError_t launch_lat<8, 4>(int, int, int, const SolveArgs &, hipStream_t);
 extern template hipError_t launch_o<1, 2>(int, int, int, const SolveArgs &, hipStream_t);
 extern template hipError_t launch_o<1, 4>(int, int, int, const SolveArgs &, hipStream_t);
 extern template hipError_t launch_o<1, 8>(int, int, int, const SolveArgs &, hipStream_t);
@@ -280,13 +186,7 @@ static hipError_t launch(const GeoSel &g, int obj, int method, int aug, const So
     if (g.nw == 1 && g.ept == 16) return launch_vec<1, 16>(obj, method, A, st); // (select_fused_geometry: SD / CG, no constraints)
     if (g.nw == 2 && g.ept == 16) return launch_vec<2, 16>(obj, method, A, st);
     if (g.nw == 4 && g.ept == 16) return launch_vec<4, 16>(obj, method, A, st);
-    if (g.nw == 2 && g.ept == 4 && method == FL_SOLVER_NEWTON) return launch_newton<2, 4>(obj, aug, A, st); // (NewtonRaphson, 256 < n <= 512)
-    if (g.nw == 2 && g.ept == 2) return launch_lat<2, 2>(obj, method, aug, A, st); // the latency geometries (select_fused_geometry)
-    if (g.nw == 2 && g.ept == 4) return launch_lat<2, 4>(obj, method, aug, A, st);
-    if (g.nw == 4 && g.ept == 2) return launch_lat<4, 2>(obj, method, aug, A, st);
-    if (g.nw == 4 && g.ept == 4) return launch_lat<4, 4>(obj, method, aug, A, st);
-    if (g.nw == 8 && g.ept == 2) return launch_lat<8, 2>(obj, method, aug, A, st);
-    if (g.nw == 8 && g.ept == 4) return launch_lat<8, 4>(obj, method, aug, A, st);
+    if (g.nw == 2 && g.ept == 4) return launch_newton<2, 4>(obj, aug, A, st);      // (select_fused_geometry: NewtonRaphson)
     if (g.nw == 1 && g.ept == 2) return launch_o<1, 2>(obj, method, aug, A, st);
     if (g.nw == 1 && g.ept == 4) return launch_o<1, 4>(obj, method, aug, A, st);
     if (g.nw == 1 && g.ept == 8) return launch_o<1, 8>(obj, method, aug, A, st);
@@ -314,7 +214,7 @@ static int solve(int method, int objective, int batch, int n, double *x, const d
     if (opt->cg_method != FL_CG_DY && opt->cg_method != FL_CG_PR) return FL_ERR_INVALID_ARGUMENT;
     GeoSel g;
     bool big = false;
-    if (!select_fused_geometry(n, method, aug != nullptr, batch, opt->geometry, g)) {
+    if (!select_fused_geometry(n, method, aug != nullptr, g)) {
         // beyond the register path: SD / CG / L-BFGS continue with vectors in HBM; the dense solvers and the
         // augmented Lagrangian do not
         if (aug || method == FL_SOLVER_NEWTON) return FL_ERR_UNSUPPORTED_SIZE;
@@ -415,7 +315,6 @@ void fl_default_options(fl_options *o, int solver)
     o->fused_f_fd = 0;
     o->clamp = 1;
     o->exact_step = 20; // NO.f90:652-653
-    o->geometry = FL_GEOMETRY_DEFAULT;
 }
 
 size_t fl_workspace_bytes_for(int solver, int batch, int n, const fl_options *opt)
@@ -468,27 +367,10 @@ int fl_reduction_geometry(int n, int *threads, int *ept)
 int fl_reduction_geometry_for(int solver, int n, int *threads, int *ept)
 {
     fl::GeoSel g;
-    if (!fl::select_throughput_geometry(n, solver, false, g)) return fl_reduction_geometry(n, threads, ept);
+    if (!fl::select_fused_geometry(n, solver, false, g)) return fl_reduction_geometry(n, threads, ept);
     if (threads) *threads = g.nw * 64;
     if (ept) *ept = g.ept;
     return FL_OK;
-}
-
-int fl_reduction_geometry_for_batch(int solver, int n, int batch, int constrained, int geometry, int *threads, int *ept)
-{
-    fl::GeoSel g;
-    if (batch <= 0) return FL_ERR_INVALID_ARGUMENT;
-    if (!fl::select_fused_geometry(n, solver, constrained != 0, batch, geometry, g)) return fl_reduction_geometry(n, threads, ept);
-    if (threads) *threads = g.nw * 64;
-    if (ept) *ept = g.ept;
-    return FL_OK;
-}
-
-int fl_set_geometry_policy(int policy)
-{
-    const int old = fl::process_geometry_policy();
-    if (policy >= FL_GEOMETRY_THROUGHPUT && policy <= FL_GEOMETRY_AUTO) fl::g_geometry_policy.store(policy, std::memory_order_relaxed);
-    return old;
 }
 
 size_t fl_workspace_bytes(int solver, int batch, int n, int memory)

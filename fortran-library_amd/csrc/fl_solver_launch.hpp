@@ -20,9 +20,6 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> constexpr int min_waves
     return FL_MIN_WPE;
 #else
     // (the quartic / Rosenbrock instances would spill 10-14 VGPRs under the cap: left alone)
-    // the latency geometries (several waves x at most 4 elements per thread: launch_lat below) run on an under-filled chip by
-    // definition -- one or two of their waves per SIMD -- so no occupancy cap is worth a spilled register there
-    if (NW >= 2 && EPT <= 4) return 1;
     if (AUG && EPT == 4 && NW <= 2 && tuned_like<OBJ>() == FL_OBJ_DIAGQUAD && (METHOD == FL_SOLVER_LBFGS || METHOD == FL_SOLVER_CG)) return 4;
     if (FL_AUG_LEAN18 && AUG && EPT == 8 && NW == 1 && tuned_like<OBJ>() == FL_OBJ_DIAGQUAD && (METHOD == FL_SOLVER_LBFGS || METHOD == FL_SOLVER_CG)) return FL_AUG18_WPE; // Solver::AUG_LEAN18 (4 waves: 80-100 spills)
     // SD / CG on them at 8 elements per thread, x0 in LDS (Solver::X0_LDS)
@@ -128,19 +125,11 @@ void fl_solve_kernel(SolveArgs A)
 // shared loop is matched by one turn of that loop; cmd (LDS, written by the master's lane 0 before the barrier that publishes
 // it) = 1: a shrink loop starts behind this barrier -- both sides then execute the same passes, the same exits, hence the
 // same barriers -- = 2: the problem is finished (a terminated wave no longer counts at s_barrier), = 0: nothing.
-#ifndef FL_REP_WPE
-#define FL_REP_WPE 3
-#endif
-// three waves per SIMD where the unhelped kernel runs three as well (Solver::AUG_LEAN18: BASELINE config 5's kernel; 3 helped
-// problems of 4 waves, or 4 of 3, per CU); 7 VGPRs go to scratch for it, none of them inside the shared loop.  The others as
-// the allocator likes (the quartic's machine at one wave x 8 would spill 40-64)
-template <int NW, int EPT, int OBJ, int METHOD> constexpr int rep_waves_per_simd()
-{
-    return (FL_AUG_LEAN18 && NW == 1 && EPT == 8 && tuned_like<OBJ>() == FL_OBJ_DIAGQUAD) ? FL_REP_WPE : 1;
-}
+// Registers: as the allocator likes (199 VGPRs for BASELINE config 5's kernel = two waves per SIMD).  Held to the unhelped
+// kernel's three waves per SIMD (168) it spills 7 VGPRs and is slower wherever helpers are used at all (batch 256: 30.7
+// against 28.2 ms with three helpers, 43.6 against 39.0 with one; profiles/r04/geometry_by_batch.txt, last two tables).
 template <int REP, int NW, int EPT, int OBJ, int METHOD, int AUG>
-__global__ __launch_bounds__(REP * NW * 64) __attribute__((amdgpu_waves_per_eu(rep_waves_per_simd<NW, EPT, OBJ, METHOD>())))
-void fl_solve_rep_kernel(SolveArgs A)
+__global__ __launch_bounds__(REP * NW * 64) void fl_solve_rep_kernel(SolveArgs A)
 {
     using S = Solver<NW, EPT, OBJ, METHOD, AUG, 0>;
     static_assert(NW == 1 && AUG && S::SPEC_K > 1, "helpers share out the speculative objective-only trials of a one-wave machine");
@@ -154,8 +143,7 @@ void fl_solve_rep_kernel(SolveArgs A)
     double *pub = lds + LT + (REP - 1) * HL, *xch = pub + PUB;
     volatile int *cmd = reinterpret_cast<volatile int *>(pub + S::PUB_DOUBLES);
     const bool lane0 = (threadIdx.x & 63) == 0, master = rep == 0;
-    // ONE machine object and ONE copy of the shared loop for both roles (two objects in two branches made the register
-    // allocator serve both paths at once: 199 VGPRs, or 64 spilled under the occupancy cap)
+    // ONE machine object and ONE copy of the shared loop for both roles
     S s(A, master ? lds : lds + LT + (rep - 1) * HL);
     if (master && lane0) *cmd = 0;
     s.init();
@@ -226,10 +214,6 @@ template <int NW, int EPT> hipError_t launch_rep(int rep, int obj, int method, c
     if (rep == 2) {
         if (obj == FL_OBJ_QUARTIC) FL_REP(2, FL_OBJ_QUARTIC);
         FL_REP(2, FL_OBJ_DIAGQUAD);
-    }
-    if (rep == 3) {
-        if (obj == FL_OBJ_QUARTIC) FL_REP(3, FL_OBJ_QUARTIC);
-        FL_REP(3, FL_OBJ_DIAGQUAD);
     }
     if (obj == FL_OBJ_QUARTIC) FL_REP(4, FL_OBJ_QUARTIC);
     FL_REP(4, FL_OBJ_DIAGQUAD);
@@ -333,31 +317,6 @@ template <int NW, int EPT> hipError_t launch_vec(int obj, int method, const Solv
     case FL_OBJ_QUARTIC: return launch_vec_m<NW, EPT, FL_OBJ_QUARTIC>(method, A, st);
     case FL_OBJ_ROSENBROCK: return launch_vec_m<NW, EPT, FL_OBJ_ROSENBROCK>(method, A, st);
     default: return launch_vec_m<NW, EPT, FL_OBJ_DIAGQUAD>(method, A, st);
-    }
-}
-
-// LATENCY geometries (fl_solver_g*l.hip): the same solvers on MORE waves x FEWER elements per thread than the throughput
-// geometry of their n, for batches that leave the chip under-filled (a GPU's share of BASELINE config 5 on eight GPUs:
-// 1024 problems on 256 CUs) -- there a problem's wall time is the latency of its trial chain, and the element-wise part of a
-// trial shrinks with the elements per thread.  The vector solvers only (SD, CG, L-BFGS; the augmented Lagrangian around
-// CG / L-BFGS): the dense ones are bound by their passes over H.  Same padded row length threads*ept as the throughput
-// geometry, so workspaces do not change; the summation order does (the oracle replays any threads x ept).
-template <int NW, int EPT, int OBJ> static hipError_t launch_lat_m(int method, int aug, const SolveArgs &A, hipStream_t st)
-{
-    if (aug) {
-        if (method == FL_SOLVER_CG) return launch_k<NW, EPT, OBJ, FL_SOLVER_CG, 1>(A, st);
-        return launch_k<NW, EPT, OBJ, FL_SOLVER_LBFGS, 1>(A, st);
-    }
-    if (method == FL_SOLVER_SD) return launch_k<NW, EPT, OBJ, FL_SOLVER_SD, 0>(A, st);
-    if (method == FL_SOLVER_CG) return launch_k<NW, EPT, OBJ, FL_SOLVER_CG, 0>(A, st);
-    return launch_k<NW, EPT, OBJ, FL_SOLVER_LBFGS, 0>(A, st);
-}
-template <int NW, int EPT> hipError_t launch_lat(int obj, int method, int aug, const SolveArgs &A, hipStream_t st)
-{
-    switch (obj) {
-    case FL_OBJ_QUARTIC: return launch_lat_m<NW, EPT, FL_OBJ_QUARTIC>(method, aug, A, st);
-    case FL_OBJ_ROSENBROCK: return launch_lat_m<NW, EPT, FL_OBJ_ROSENBROCK>(method, aug, A, st);
-    default: return launch_lat_m<NW, EPT, FL_OBJ_DIAGQUAD>(method, aug, A, st);
     }
 }
 

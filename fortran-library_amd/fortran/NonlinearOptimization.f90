@@ -32,9 +32,8 @@ module NonlinearOptimization
     type,bind(C)::fl_options!include/fl_nlopt.h: struct fl_options
         integer(c_int32_t)::strong,max_iteration
         real(c_double)::precision,min_step_length,wolfe_c1,wolfe_c2,increment
-        integer(c_int32_t)::memory,cg_method,fused_f_fd,clamp,exact_step,geometry
+        integer(c_int32_t)::memory,cg_method,fused_f_fd,clamp,exact_step
     end type fl_options
-    integer(c_int),parameter::FL_GEOMETRY_DEFAULT=0,FL_GEOMETRY_THROUGHPUT=1,FL_GEOMETRY_LATENCY=2,FL_GEOMETRY_AUTO=3
 
     interface
         subroutine flc_steepestdescent(f,fd,x,dim,f_fd,Strong,Warning,MaxIteration,Precision,MinStepLength,&

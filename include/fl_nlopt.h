@@ -81,25 +81,7 @@ typedef struct fl_options {
                              /* recomputed (NO.f90:630-631, default 20; <= 0 never).  The batched  */
                              /* solvers use the built-in objective's analytic Hessian (the fdd     */
                              /* branch, NO.f90:675, 951); reverse communication runs <= 0 only     */
-    int32_t geometry;        /* FL_GEOMETRY_*: which reduction geometry the fused kernels take for a batch */
-                             /* (below).  FL_GEOMETRY_DEFAULT (0, and any value out of range -- the field   */
-                             /* occupies what was tail padding, sizeof stays 72) = the process policy       */
 } fl_options;
-
-/* Geometry policy of the fused kernels (SD / CG / L-BFGS and the augmented Lagrangian around CG / L-BFGS, 128 < n <= 2048):
- *   FL_GEOMETRY_THROUGHPUT  the geometry of n alone (fl_reduction_geometry_for): tuned for a chip full of problems; results
- *                           are bit-identical whatever the batch size or the sharding
- *   FL_GEOMETRY_LATENCY     more waves x fewer elements per thread per problem: the shortest wall time of ONE problem
- *   FL_GEOMETRY_AUTO        by batch: a latency geometry while the batch leaves the device under-filled (a GPU's share of a
- *                           strong-scaled batch), else the throughput geometry -- the process default
- * fl_set_geometry_policy sets the process policy (returns the previous one; FL_GEOMETRY=throughput|latency|auto in the
- * environment sets the initial one).  The padded row length threads*ept -- hence every workspace size -- is the same under
- * all policies; the summation order of the dot products (and with it the last bits of a result) follows the geometry. */
-#define FL_GEOMETRY_DEFAULT 0
-#define FL_GEOMETRY_THROUGHPUT 1
-#define FL_GEOMETRY_LATENCY 2
-#define FL_GEOMETRY_AUTO 3
-int fl_set_geometry_policy(int policy);
 
 #define FL_SOLVER_SD 0
 #define FL_SOLVER_CG 1
@@ -125,10 +107,6 @@ int fl_reduction_geometry(int n, int *threads, int *ept);
  * history to keep, the state fits) and FL_SOLVER_NEWTON 256 < n <= 512 with two waves x 4 (its Cholesky wants the threads).  threads*ept -- the padded length of every workspace row -- is the same for all solvers of
  * an n; the reverse-communication kernels (fl_rci_*) and the dense routines use fl_reduction_geometry's. */
 int fl_reduction_geometry_for(int solver, int n, int *threads, int *ept);
-/* The geometry the fused kernel takes for `batch` problems on the current device: solver as above, constrained != 0 for the
- * augmented Lagrangian around it, geometry = an FL_GEOMETRY_* value as in fl_options (FL_GEOMETRY_DEFAULT: the process
- * policy).  What tests hand to the oracle to replay a result bit for bit, and what bench.py reports per leg. */
-int fl_reduction_geometry_for_batch(int solver, int n, int batch, int constrained, int geometry, int *threads, int *ept);
 
 /* The fused L-BFGS kernel keeps the newest pairs of its (s, y) ring on the chip (registers, then an LDS ring); this
  * returns how many for a built-in objective and dimension n (0 beyond n = 4096).  With C of them on the chip an

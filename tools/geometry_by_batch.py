@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Wall time of the fused kernels by batch size and reduction geometry (MI355X, one GPU): the table behind the break-even
-batches of FL_GEOMETRY_AUTO (csrc/fl_solver_kernels.hip: latency_candidates) -> profiles/r04/geometry_by_batch.txt.
+"""Wall time of the fused kernels by batch size and waves per problem (MI355X, one GPU): the table behind the break-even
+batches of the helper-wave kernels (csrc/fl_solver_kernels.hip: select_replicas) -> profiles/r04/geometry_by_batch.txt.
 
-For every workload and batch the same problems (the first `batch` of the benched family) are solved under the throughput
-geometry of n and under each latency candidate (FL_FORCE_GEOMETRY, read by the library per call), three launches each,
-the minimum kept (HIP events on the launch stream).  Iteration totals are printed too: geometries differ in summation
-order, so their paths differ in the last bits and a handful of iterations.
+For every workload and batch the same problems (the first `batch` of the benched family) are solved by the plain kernel and
+with 1 / 3 helper waves ("r2" / "r4": FL_FORCE_REPLICAS, read by the library per call), three launches each, the minimum kept
+(HIP events on the launch stream).  (At commit ca4f3a1 this tool also forced the latency geometries 2x2 .. 8x4 that round 4
+measured and dropped: FL_FORCE_GEOMETRY; those columns of the committed table come from there.)
 usage: python tools/geometry_by_batch.py [c5 headline c3 c2 lbfgs512 cg512 lbfgs2048] [--batches 256,1024,2048,4096,8192]
 """
 import argparse
@@ -59,7 +59,7 @@ def workload(name, B):
         def run():
             x.copy_(x0)
             return NLO.AugmentedLagrangian(NLO.DIAGQUAD, x, M, d, b, UnconstrainedSolver="LBFGS", workspace_=ws, Precision=1e-10, Memory=m)
-        return run, ["1x8", "2x4", "4x2", "1x8r2", "1x8r3", "1x8r4"]
+        return run, ["1x8", "1x8r2", "1x8r4"]
     if name in ("headline", "lbfgs512", "lbfgs256", "lbfgs2048"):
         n = {"headline": 1024, "lbfgs512": 512, "lbfgs256": 256, "lbfgs2048": 2048}[name]
         d, b = quad(B, n, 10.0, 1000.0)
@@ -69,7 +69,7 @@ def workload(name, B):
         def run():
             x.zero_()
             return NLO.LBFGS(NLO.DIAGQUAD, x, d, b, workspace_=ws, Precision=1e-6, MaxIteration=3000)
-        return run, {1024: ["2x8", "4x4", "8x2"], 512: ["1x8", "2x4", "4x2"], 256: ["1x4", "2x2"], 2048: ["4x8", "8x4"]}[n]
+        return run, {1024: ["2x8"], 512: ["1x8"], 256: ["1x4"], 2048: ["4x8"]}[n]
     if name in ("c3", "cg512"):
         n = 1024 if name == "c3" else 512
         d, b = quad(B, n, 10.0, 1000.0)
@@ -78,7 +78,7 @@ def workload(name, B):
         def run():
             x.zero_()
             return NLO.ConjugateGradient(NLO.DIAGQUAD, x, d, b, Precision=1e-6, MaxIteration=3000)
-        return run, (["1x16", "4x4", "8x2"] if n == 1024 else ["1x8", "2x4", "4x2"])
+        return run, (["1x16"] if n == 1024 else ["1x8"])
     if name == "c2":
         n, m = 256, 10
         x0 = torch.empty(B, n, dtype=torch.float64, device=dev)
@@ -89,7 +89,7 @@ def workload(name, B):
         def run():
             x.copy_(x0)
             return NLO.LBFGS(NLO.ROSENBROCK, x, workspace_=ws, Precision=1e-10, MaxIteration=3000, Memory=m)
-        return run, ["1x4", "2x2"]
+        return run, ["1x4"]
     raise SystemExit("unknown workload " + name)
 
 

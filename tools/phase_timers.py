@@ -3,7 +3,7 @@
 run with FL_LIBRARY=<that file>): BASELINE config 5's family at --batch problems under each geometry; prints, for the slowest
 problem and the mean, time (ms) and calls in: fast_forward (tight objective-only loop), fast_forward_grow, objective-only
 evaluation, full evaluation, advance() inside a search, advance() ending a search (convergence tests + new direction = the
-two-loop recursion).  usage: FL_LIBRARY=.../libFL_timers.so python tools/phase_timers.py [--batch 1024] [--geos 1x8,2x4,4x2]"""
+two-loop recursion).  usage: FL_LIBRARY=.../libFL_timers.so python tools/phase_timers.py [--batch 1024] """
 import argparse, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "fortran-library_amd")); sys.path.insert(0, ROOT)
@@ -16,7 +16,7 @@ from geometry_by_batch import workload
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=1024)
 ap.add_argument("--workload", default="c5")
-ap.add_argument("--geos", default="1x8,2x4,4x2")
+ap.add_argument("--geos", default="1x8")
 a = ap.parse_args()
 names = ["fast_forward", "fast_forward_grow", "eval_f", "eval_fg", "advance_in_search", "advance_direction"]
 run, _ = workload(a.workload, a.batch)
