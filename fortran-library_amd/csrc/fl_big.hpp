@@ -64,7 +64,8 @@ template <int OBJ, int METHOD> struct BigSolver {
     // oracle's tree order with `groups` (oracle/fl_oracle.c: tree_reduce).  G = 1: everything as before.
     int G, wg, c_lo, c_hi;
     double *coop_part;       // [2][G][NVMAX] partial sums of this problem's workgroups (two generations)
-    unsigned *coop_counter;  // arrivals at this problem's barriers (zeroed by the host before every launch)
+    unsigned *coop_counter;  // arrivals at this problem's barriers (zeroed by the host before every launch); word 1: gave up
+    unsigned *coop_host_flag; // the handle's host-visible "a barrier gave up" word (pinned host memory), may be NULL
     unsigned coop_gen;
 
     __host__ __device__ static int slots_for(int n) { return ((n + 1) / 2 + T - 1) / T; }
@@ -92,6 +93,7 @@ template <int OBJ, int METHOD> struct BigSolver {
         c_hi = nslot;
         coop_part = nullptr;
         coop_counter = nullptr;
+        coop_host_flag = nullptr;
         coop_gen = 0;
     }
     __host__ __device__ static int coop_slots_per_group(int n, int groups) { return (slots_for(n) + groups - 1) / groups; }
@@ -102,7 +104,7 @@ template <int OBJ, int METHOD> struct BigSolver {
         const int per = coop_slots_per_group(n, groups);
         return (slots_for(n) + per - 1) / per;
     }
-    __device__ __forceinline__ void set_cooperative(int groups, int group, double *part, unsigned *counter)
+    __device__ __forceinline__ void set_cooperative(int groups, int group, double *part, unsigned *counter, unsigned *host_flag = nullptr)
     {
         G = groups;
         wg = group;
@@ -111,32 +113,45 @@ template <int OBJ, int METHOD> struct BigSolver {
         c_hi = c_lo + per < nslot ? c_lo + per : nslot;
         coop_part = part;
         coop_counter = counter;
+        coop_host_flag = host_flag;
     }
     // Every workgroup of the problem has arrived.  What crosses workgroups -- the partial sums and this counter -- moves by
-    // device-scope atomics (they bypass the XCDs' private L2s); vector elements never cross (each is touched by its owner
-    // alone, and a kernel boundary lies between two steps).  So the ordering needs no device-wide fence -- a
-    // __threadfence() here writes the whole XCD's dirty L2 back: measured ~60 us per barrier -- only that thread 0's
-    // partial-sum stores have completed before its arrival is counted (workgroup-scope release = wait for the stores).
+    // device-scope atomics (they bypass the XCDs' private L2s: /opt/skills/guides/MI355X_MICROARCH.md, "cross-workgroup
+    // hand-off", the flag / counter recipe); vector elements never cross (each is touched by its owner alone, and a kernel
+    // boundary lies between two steps).  So the ordering needs no device-wide fence -- a __threadfence() here writes the
+    // whole XCD's dirty L2 back: measured ~60 us per barrier, and an agent-scope RELEASE on the counter emits the same
+    // write-back -- only this: thread 0's partial-sum stores (write-through, `sc1`) must have LEFT THE WAVE'S STORE QUEUE
+    // before its arrival is counted.  A workgroup-scope fence does not wait for them (round 3 relied on it: the ISA had the
+    // stores, s_barrier and the atomic add with no wait in between, so a sibling could see the count reached and read a
+    // partial sum from two generations ago) -- the explicit s_waitcnt vmcnt(0) does (gfx9: stores count in vmcnt), and
+    // tests/test_kernel_resources.py checks that it is in the code object between the stores and the add.  On the other
+    // side the partial sums are fetched by agent-scope loads issued behind the workgroup barrier that follows the poll.
+    // Bounded wait: should the workgroups of a problem ever not be resident together (fl_rci_create sizes the grid from the
+    // occupancy query, but a GPU shared with another process can still break it) the wait ends, the problem's flag word
+    // and the handle's host-visible word are set, every later barrier of the problem returns at once (the counter can
+    // never catch up), and the next fl_rci_step / fl_rci_results reports FL_ERR_LAUNCH.
     __device__ __forceinline__ void coop_barrier()
     {
         __syncthreads();
         ++coop_gen; // (every thread counts the barriers: the generation picks the partial sums' buffer in reduce())
         if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the partial sums have reached memory
             __hip_atomic_fetch_add(coop_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned want = coop_gen * (unsigned)G;
-            // (bounded: should the workgroups of a problem ever not be resident together -- a GPU shared with another
-            // process -- the wait ends after a few seconds, the handle is flagged and fl_rci_results reports it, instead of
-            // a kernel that never finishes)
-            unsigned spins = 0;
-            while (__hip_atomic_load(coop_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1u << 22)) {
-                    __hip_atomic_store(coop_counter + 1, 0xdeadu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (the flag word)
-                    break;
+            if (__hip_atomic_load(coop_counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) { // (nobody gave up yet)
+                unsigned spins = 0;
+                while (__hip_atomic_load(coop_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                    __builtin_amdgcn_s_sleep(1);
+                    ++spins;
+                    if ((spins & 1023u) == 0u && __hip_atomic_load(coop_counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+                        break; // a sibling gave up
+                    if (spins > (1u << 22)) {
+                        __hip_atomic_store(coop_counter + 1, 0xdeadu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (coop_host_flag) __hip_atomic_store(coop_host_flag, 0xdeadu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
         __syncthreads();
     }

@@ -100,15 +100,17 @@ void __linearalgebra_MOD_my_dsyev(const char *jobtype, double *A, double *eigval
     int sweeps = 0;
     // dsyev scales a matrix whose norm is close to the under/overflow thresholds before it squares anything (dlascl);
     // here: by a power of two (exact) to max |a_ij| ~ 1 when that maximum is outside [1e-100, 1e100]
-    double amax = 0.0, scale = 1.0;
+    double amax = 0.0;
+    int scale_exp = 0; // the matrix is solved as A * 2^scale_exp (scalbn: exact, and no intermediate 2^e that could overflow -- a matrix of
+                       // subnormals, max |a_ij| < 2^-1022, has e > 1023)
     for (int j = 0; j < n; ++j)
         for (int i = j; i < n; ++i) amax = std::max(amax, std::fabs(A[(size_t)j * n + i])); // 'L': the lower triangle
     std::vector<double> scaled;
     const double *src = A;
     if (std::isfinite(amax) && amax > 0.0 && (amax < 1e-100 || amax > 1e100)) {
-        scale = std::scalbn(1.0, -std::ilogb(amax));
+        scale_exp = -std::ilogb(amax);
         scaled.resize((size_t)n * n);
-        for (size_t k = 0; k < (size_t)n * n; ++k) scaled[k] = A[k] * scale;
+        for (size_t k = 0; k < (size_t)n * n; ++k) scaled[k] = std::scalbn(A[k], scale_exp);
         src = scaled.data();
     }
     bool ok = Ad.p && Wd.p && ws.p && hipMemcpy(Ad.p, src, a, hipMemcpyHostToDevice) == hipSuccess;
@@ -148,7 +150,7 @@ void __linearalgebra_MOD_my_dsyev(const char *jobtype, double *A, double *eigval
     std::vector<int> order(n);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return w[x] < w[y]; });
-    for (int k = 0; k < n; ++k) eigval[k] = w[order[k]] / scale;
+    for (int k = 0; k < n; ++k) eigval[k] = scale_exp ? std::scalbn(w[order[k]], -scale_exp) : w[order[k]];
     if (vec && !vectors_in_A)
         for (int k = 0; k < n; ++k) std::copy(V.begin() + (size_t)order[k] * n, V.begin() + (size_t)(order[k] + 1) * n, A + (size_t)k * n);
 }

@@ -13,12 +13,36 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 
 #include "../../include/fl_nlopt.h"
 
+extern "C" void fl_internal_set_concurrent_batch(int problems); // (csrc/fl_solver_kernels.hip; not part of the public ABI)
+
 namespace {
+
+// The caller's big arrays are pageable memory: the runtime stages every copy through its own pinned buffers (2.1 GB of the
+// headline batch: 43 of 198 ms, profiles/r03/host_arrays.txt).  FL_MULTI_PIN=1 in the environment registers them
+// (page-locked in place, hipHostRegister) for the duration of the call, so that the shards' 2D copies go by DMA straight
+// from / to them -- best effort: a range that cannot be registered is copied the old way.  OFF by default: measured on the
+// headline batch (profiles/r04/host_arrays.txt) the registration of 1.6 GB costs what the faster copies save (default
+// shards 201.5 against 205.3 ms, one shard 224.3 against 227.4, eight shards 204.4 against 198.1): the call is bound by the
+// 2.1 GB crossing PCIe (~40 ms at 55 GB/s), most of which the shards of a device already overlap with each other's solves.
+struct Pinned {
+    std::vector<void *> ranges;
+    void add(const void *p, size_t bytes)
+    {
+        if (!p || bytes < ((size_t)8 << 20)) return; // (small arrays: the registration costs more than it saves)
+        if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) == hipSuccess) ranges.push_back(const_cast<void *>(p));
+        else (void)hipGetLastError();
+    }
+    ~Pinned()
+    {
+        for (void *p : ranges) (void)hipHostUnregister(p);
+    }
+};
 
 struct Job {
     int solver, objective, batch, n, aug_m, nshards, interleaved;
@@ -59,20 +83,24 @@ template <class T> bool rows_d2h(T *dst, const T *src, int first, int step, int 
                             (size_t)width * sizeof(T), count, hipMemcpyDeviceToHost, st) == hipSuccess;
 }
 
+// shard s of J: its first problem and how many it holds (rows first, first + step, ...; step = nshards when interleaved)
+int shard_first(const Job &J, int s)
+{
+    if (J.interleaved) return s;
+    const int per = (J.batch + J.nshards - 1) / J.nshards;
+    return std::min(J.batch, s * per);
+}
+int shard_count(const Job &J, int s)
+{
+    if (J.interleaved) return s < J.batch ? (J.batch - s + J.nshards - 1) / J.nshards : 0;
+    const int per = (J.batch + J.nshards - 1) / J.nshards, first = shard_first(J, s);
+    return std::min(J.batch, first + per) - first;
+}
+
 int run_shard(const Job &J, int shard, int device)
 {
     const int S = J.nshards, n = J.n;
-    int first, step, count;
-    if (J.interleaved) {
-        first = shard;
-        step = S;
-        count = shard < J.batch ? (J.batch - shard + S - 1) / S : 0;
-    } else {
-        const int per = (J.batch + S - 1) / S;
-        first = std::min(J.batch, shard * per);
-        step = 1;
-        count = std::min(J.batch, first + per) - first;
-    }
+    const int first = shard_first(J, shard), step = J.interleaved ? S : 1, count = shard_count(J, shard);
     if (count <= 0) return FL_OK;
     if (hipSetDevice(device) != hipSuccess) return FL_ERR_NO_DEVICE;
     hipStream_t st;
@@ -165,15 +193,47 @@ int fl_multi_solve(int solver, int objective, int batch, int n, double *x_host, 
     (void)hipGetDevice(&prev);
     Job J{solver, objective, batch, n, aug_m, S, interleaved != 0, x_host, d_host, b_host, opt, lambda_host, miu0,
           f_host, gg_host, cnorm2_host, iters_host, outer_host, status_host, nf_host, ng_host};
-    std::vector<int> rc(S, FL_OK);
+    Pinned pin;
+    {
+        const char *e = std::getenv("FL_MULTI_PIN");
+        if (e && e[0] == '1') {
+            const size_t bytes = (size_t)batch * n * sizeof(double);
+            pin.add(x_host, bytes);
+            pin.add(d_host, bytes);
+            pin.add(b_host, bytes);
+        }
+    }
+    std::vector<int> rc(S, FL_ERR_LAUNCH); // (a shard whose thread could not even be started stays "failed")
     std::vector<std::thread> th;
     th.reserve(S);
-    for (int s = 0; s < S; ++s) th.emplace_back([&, s] { rc[s] = run_shard(J, s, s % ndev); });
+    // how many problems each device holds at once: the shards of a device run concurrently, so a kernel's choices by batch
+    // size (helper waves: fl_solver_kernels.hip, select_replicas) must see the device's load, not the shard's
+    std::vector<int> dev_load(ndev, 0);
+    for (int s = 0; s < S; ++s) dev_load[s % ndev] += shard_count(J, s);
+    for (int s = 0; s < S; ++s) {
+        try {
+            th.emplace_back([&, s] {
+                fl_internal_set_concurrent_batch(dev_load[s % ndev]);
+                rc[s] = run_shard(J, s, s % ndev);
+                fl_internal_set_concurrent_batch(0);
+            });
+        } catch (...) { // (std::system_error: no more threads) -- the shards already started finish, the rest are reported
+            break;
+        }
+    }
     for (auto &t : th) t.join();
     (void)hipSetDevice(prev);
-    for (int s = 0; s < S; ++s)
-        if (rc[s] != FL_OK) return rc[s];
-    return FL_OK;
+    int first_error = FL_OK;
+    for (int s = 0; s < S; ++s) {
+        if (rc[s] == FL_OK) continue;
+        if (first_error == FL_OK) first_error = rc[s];
+        // which rows hold results and which still hold the initial guesses: the failed shards' status rows say so
+        if (status_host) {
+            const int first = J.interleaved ? s : shard_first(J, s), step = J.interleaved ? S : 1, count = shard_count(J, s);
+            for (int k = 0; k < count; ++k) status_host[(size_t)first + (size_t)k * step] = FL_STATUS_NOT_SOLVED;
+        }
+    }
+    return first_error;
 }
 
 } // extern "C"

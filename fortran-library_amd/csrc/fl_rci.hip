@@ -123,14 +123,14 @@ template <int METHOD>
 __global__ __launch_bounds__(1024) void rci_step_big_kernel(SolveArgs A, int first, double *sc_all, double *vec_all,
                                                             double *rho_all, const double *f_dev, const double *g_dev,
                                                             int32_t *request, int groups, double *coop_part,
-                                                            unsigned *coop_counter, int parity)
+                                                            unsigned *coop_counter, int parity, unsigned *coop_host_flag)
 {
     using S = BigSolver<FL_OBJ_EXTERNAL, METHOD>;
     __shared__ __attribute__((aligned(16))) double lds[S::LDS_TOTAL];
     const int prob = blockIdx.x / groups, group = blockIdx.x - prob * groups, n = A.n;
     S s(A, lds, vec_all, prob);
     if (groups > 1)
-        s.set_cooperative(groups, group, coop_part + (size_t)prob * 2 * groups * Reducer<S::NW>::NVMAX, coop_counter + 2 * prob);
+        s.set_cooperative(groups, group, coop_part + (size_t)prob * 2 * groups * Reducer<S::NW>::NVMAX, coop_counter + 2 * prob, coop_host_flag);
     // cooperative form: the scalars (and the rho ring) are parked in two copies used alternately -- this step reads copy
     // `parity` and its first workgroup writes the other one, so no workgroup can see a half-written block and no barrier
     // is needed between load() and save() (a step that only takes an objective value has none of its own)
@@ -288,7 +288,8 @@ struct Rci {
     int coop_groups;        // vectors-in-HBM path: workgroups per problem (BigSolver's cooperative form), 1 = none
     int parity;             // ... which copy of the parked scalars the next step reads
     double *coop_part;      // [batch][2][groups][NVMAX]
-    unsigned *coop_counter; // [batch]
+    unsigned *coop_counter; // [batch][2]: arrivals, "gave up" flag
+    unsigned *coop_flag_host, *coop_flag_dev; // one pinned word the kernels set when a cooperative barrier gave up (+ its device address)
 };
 
 template <int NW, int EPT>
@@ -332,7 +333,7 @@ static void launch_rci_big(Rci *h, const double *f, const double *g, int32_t *re
     dim3 grid(h->batch * G), block(1024);
 #define FL_RCI(M)                                                                                                 \
     hipLaunchKernelGGL((rci_step_big_kernel<M>), grid, block, 0, h->stream, h->A, h->first, h->sc, h->vec, h->rho, f, \
-                       g, req, G, h->coop_part, h->coop_counter, h->parity)
+                       g, req, G, h->coop_part, h->coop_counter, h->parity, h->coop_flag_dev)
     switch (h->solver) {
     case FL_SOLVER_SD: FL_RCI(FL_SOLVER_SD); break;
     case FL_SOLVER_CG: FL_RCI(FL_SOLVER_CG); break;
@@ -356,6 +357,7 @@ int fl_rci_destroy(fl_rci *h)
     if (!h) return FL_OK;
     if (h->r.coop_part) (void)hipFree(h->r.coop_part);
     if (h->r.coop_counter) (void)hipFree(h->r.coop_counter);
+    if (h->r.coop_flag_host) (void)hipHostFree(h->r.coop_flag_host);
     void *bufs[] = {h->r.sc, h->r.vec, h->r.rho, h->r.ws, h->r.f_out, h->r.gg_out, h->r.iters, h->r.status,
                     h->r.nf, h->r.ng, h->r.outer, h->r.cnorm2};
     for (void *b : bufs)
@@ -437,6 +439,23 @@ int fl_rci_create(fl_rci **out, int solver, int batch, int n, const fl_options *
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
         if (cus > BS::COOP_MAX_GROUPS) cus = BS::COOP_MAX_GROUPS;
+        // the barriers of the cooperative form SPIN: all batch x G workgroups must be resident together.  The grid is sized
+        // from what the runtime says fits (workgroups of this very kernel per CU x CUs), not from an assumption
+        int per_cu = 0;
+        {
+            hipError_t eo = hipErrorUnknown;
+            switch (solver) {
+            case FL_SOLVER_SD: eo = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fl::rci_step_big_kernel<FL_SOLVER_SD>, 1024, 0); break;
+            case FL_SOLVER_CG: eo = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fl::rci_step_big_kernel<FL_SOLVER_CG>, 1024, 0); break;
+            default: eo = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fl::rci_step_big_kernel<FL_SOLVER_LBFGS>, 1024, 0); break;
+            }
+            if (eo != hipSuccess || per_cu < 1) {
+                (void)hipGetLastError();
+                per_cu = 0; // (no answer: no cooperative form)
+            }
+            if (per_cu > 1) per_cu = 1; // one workgroup per CU: a sibling on the same CU would share its LDS pipe for nothing
+        }
+        cus *= per_cu;
         int want = cus / batch;
         const int nslot = BS::slots_for(n);
         if (want > nslot / 2) want = nslot / 2;
@@ -446,7 +465,12 @@ int fl_rci_create(fl_rci **out, int solver, int batch, int n, const fl_options *
             r.coop_groups = BS::coop_groups(n, want);
             ok = hipMalloc((void **)&r.coop_part, B * 2 * r.coop_groups * fl::Reducer<16>::NVMAX * sizeof(double)) == hipSuccess &&
                  hipMalloc((void **)&r.coop_counter, 2 * B * sizeof(unsigned)) == hipSuccess &&
-                 hipMemsetAsync(r.coop_counter, 0, 2 * B * sizeof(unsigned), r.stream) == hipSuccess;
+                 hipMemsetAsync(r.coop_counter, 0, 2 * B * sizeof(unsigned), r.stream) == hipSuccess &&
+                 hipHostMalloc((void **)&r.coop_flag_host, sizeof(unsigned), hipHostMallocMapped) == hipSuccess;
+            if (ok) {
+                *r.coop_flag_host = 0u;
+                ok = hipHostGetDevicePointer((void **)&r.coop_flag_dev, r.coop_flag_host, 0) == hipSuccess;
+            }
         }
     }
     if (!ok) {
@@ -481,6 +505,8 @@ static int rci_step_any(fl_rci *h, double *x_dev, const double *f_dev, const dou
     double *xio = xc_dev ? xc_dev : x_dev;
     if (nw == 16) {
         if (active_dev || flags) return FL_ERR_UNSUPPORTED_SIZE; // (the vectors-in-HBM path steps whole batches)
+        // a cooperative barrier of an earlier step gave up (its siblings were not resident): nothing since can be trusted
+        if (r->coop_flag_host && *(volatile unsigned *)r->coop_flag_host != 0u) return FL_ERR_LAUNCH;
         fl::launch_rci_big(r, f_dev, g_dev, request_dev);
     }
     else if (nw == 1 && ept == 2) fl::launch_rci<1, 2>(r, f_dev, g_dev, c_dev, cd_dev, request_dev, flags, active_dev, nactive, xio);

@@ -143,8 +143,11 @@ static int device_compute_units()
 #define FL_REP4_MAX_BATCH 1280 // (problems per 256 CUs)
 #define FL_REP2_MAX_BATCH 2560
 #endif
+// (fl_multi_solve runs several shards on one device at once: each of its threads says how many problems the device holds)
+static thread_local int tls_concurrent_batch = 0;
 static int select_replicas(const GeoSel &g, int objective, int method, int n, int m, int batch)
 {
+    if (tls_concurrent_batch > batch) batch = tls_concurrent_batch;
     if (g.nw != 1 || (g.ept != 8 && g.ept != 4)) return 1;
     if (objective != FL_OBJ_DIAGQUAD && objective != FL_OBJ_QUARTIC) return 1;
     if (method != FL_SOLVER_LBFGS && method != FL_SOLVER_CG) return 1;
@@ -298,7 +301,9 @@ template <int NW, int EPT> static int onchip_pairs_o(int obj)
 
 extern "C" {
 
-int fl_version(void) { return 102; }
+int fl_version(void) { return 103; }
+
+void fl_internal_set_concurrent_batch(int problems) { fl::tls_concurrent_batch = problems > 0 ? problems : 0; }
 
 void fl_default_options(fl_options *o, int solver)
 {

@@ -54,6 +54,8 @@ extern "C" {
 #define FL_STATUS_CONVERGED 0      /* g.g < Precision^2                   (NO.f90:612)          */
 #define FL_STATUS_STEP_CONVERGED 1 /* p.p a^2 < MinStepLength^2 "step length has converged" (NO.f90:615) */
 #define FL_STATUS_MAXIT 2          /* MaxIteration exceeded              (NO.f90:580)           */
+#define FL_STATUS_NOT_SOLVED (-1)  /* fl_multi_solve only: the shard holding this problem failed (allocation, launch); */
+                                   /* its rows of x and of the outputs are untouched                                  */
 
 #define FL_CG_DY 0 /* Dai-Yuan        NO.f90:352-372 */
 #define FL_CG_PR 1 /* Polak-Ribiere+  NO.f90:373-393 */
@@ -262,7 +264,11 @@ int fl_augmented_lagrangian_batched(int solver, int objective, int batch, int n,
  *   nshards    <= 0: up to four shards per visible device (while a shard keeps >= 4096 problems: the shards of a device
  *              overlap each other's transfers and solves); more shards than devices share devices round-robin
  *   interleaved  0: contiguous blocks of ceil(batch / nshards) problems;  1: problem k -> shard k mod nshards
- * Every output pointer may be NULL.  Results do not depend on the sharding (one workgroup owns one problem either way). */
+ * Every output pointer may be NULL.  Results do not depend on the sharding (one workgroup owns one problem either way).
+ * FL_MULTI_PIN=1 in the environment page-locks the big host arrays (x, d, b) in place for the duration of the call
+ * (hipHostRegister, best effort) so that the shards' copies go by DMA; off by default (measured: no gain, csrc/fl_multi.cpp).
+ * Return: FL_OK, or the first failing shard's error; then status_host (if given) carries FL_STATUS_NOT_SOLVED in the rows
+ * of the shards that failed -- their rows of x_host and of the other outputs are untouched, every other row is final. */
 int fl_multi_device_count(void);
 int fl_multi_solve(int solver, int objective, int batch, int n, double *x_host, const double *d_host, const double *b_host,
                    const fl_options *opt, int aug_m, double *lambda_host, double miu0, double *f_host, double *gg_host,

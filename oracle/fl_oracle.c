@@ -775,6 +775,7 @@ int flo_dsysv(double *A, double *b, int n)
 int flo_lagrangian_multiplier(flo_fd_t fd, flo_fdd_t fdd, flo_c_t c, flo_cd_t cd, flo_cdd_t cdd, double *x,
                               double *lambda, int n, int m, int maxit, double precision, void *ctx)
 {
+    if (!fd || !fdd || !c || !cd || !cdd || !x) return -1; /* all five callbacks are mandatory in the reference too (NO.f90:1950-1952) */
     const int dim = n + m;
     size_t N = (size_t)n, D = (size_t)dim;
     const double tol = precision * precision;

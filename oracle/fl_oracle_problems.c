@@ -200,6 +200,11 @@ int flo_auglag_batch(int solver, int kind, int B, int n, int m, double *x, const
                      double *cnorm2)
 {
     int used = 1;
+    /* a checker must not crash on the arguments a test hands it (round 3, gpurun_out/r03_t13.log: a NULL fdd reached
+     * flo_newton from here and every OpenMP thread called it): refuse what cannot be run, with a code */
+    if (!x || !lambda || !o || B < 0 || n <= 0 || m <= 0 || m > n) return -1;
+    if (kind == FLO_DIAGQUAD && (!d || !b)) return -1;
+    if (solver != FLO_LBFGS && solver != FLO_CG && solver != FLO_BFGS && solver != 4) return -1;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
     used = omp_get_max_threads();

@@ -108,4 +108,6 @@ def auglag_batch(solver, kind, x0, m, d=None, b=None, lambda0=None, miu0=1.0, op
     used = lib().flo_auglag_batch(solver, kind, B, n, m, _dp(x), _dp(d), _dp(b), _dp(lam), miu0, C.byref(o),
                                   int(use_ffd), sum_mode, threads, ept, nthreads, _dp(f), _ip(it), _ip(outer),
                                   _ip(nf), _ip(ng), _dp(cc))
+    if used < 0:
+        raise ValueError("flo_auglag_batch refused its arguments")
     return dict(x=x, f=f, iters=it, outer=outer, nf=nf, ng=ng, cnorm2=cc, lam=lam, threads=used)

@@ -249,6 +249,7 @@ def _eig_cases(n, seed):
         "near_clusters": (Q * (rep + 1e-13 * rng.standard_normal(n))[None, :]) @ Q.T,        # ... split at the 1e-13 level
         "tiny": 1e-200 * 0.5 * (G + G.T),                                                     # squares underflow / overflow
         "huge": 1e+200 * 0.5 * (G + G.T),
+        "subnormal": 1e-310 * 0.5 * (G + G.T),                                                # max |a_ij| < 2^-1022: the scaling factor itself must not overflow
         # numerically rank deficient: a null cluster of ~n - 20 eigenvalues right below genuine ones at 1e-14, 1e-13, ...
         # (shifts chained upwards walked into those and hundreds of vectors collapsed: invit_shift_kernel)
         "hilbert": 1.0 / (np.arange(n)[:, None] + np.arange(n)[None, :] + 1.0),
@@ -261,11 +262,14 @@ def _eig_cases(n, seed):
 
 
 def _check_basis(name, A, S, w, n):
-    norm = max(np.abs(A).sum(axis=1).max(), 1e-300)
-    An, wn = A / norm, w / norm  # (the extreme scalings would overflow in the products below)
+    norm = np.abs(A).sum(axis=1).max()
+    e = -int(np.floor(np.log2(norm))) if norm > 0 else 0
+    An, wn = np.ldexp(A, e), np.ldexp(w, e)  # (exact; the extreme scalings would under / overflow in the products below)
     ref = np.linalg.eigvalsh(An)
     assert np.all(np.diff(w) >= 0), name
-    assert np.abs(wn - ref).max() <= 4 * max(n, 4) * 2.3e-16, (name, np.abs(wn - ref).max())
+    # (eigenvalues that are subnormal numbers themselves carry fewer bits: 1e-310 has 44, i.e. 3e-14 relative)
+    wtol = 1e-13 if name == "subnormal" else 4 * max(n, 4) * 2.3e-16
+    assert np.abs(wn - ref).max() <= wtol, (name, np.abs(wn - ref).max())
     # the bar of the library's own device-side check (512 eps on the tridiagonal's vectors) plus the two orthogonal
     # transformations around it; typical figures are ~1e-16 (residual) and ~2e-15 (orthogonality), see DESIGN.md 8
     bar = max(600, 4 * n) * 2.3e-16
@@ -286,7 +290,7 @@ def test_my_dsyev_with_vectors_edge_cases(n):
         _check_basis(name, A, S, w, n)
 
 
-@pytest.mark.parametrize("n", [5, 64, 200, 1024, 1100, 2500])
+@pytest.mark.parametrize("n", [5, 64, 200, 1024, 1100, 2500, 3072, 4096])
 def test_fl_dsyev_vectors_passes_its_own_check_and_reports_it(n):
     """the device entry itself: FL_OK (not the Jacobi fallback) on every case but the extreme scalings, which the legacy
     symbol rescales first (dsyev's dlascl) and the device entry reports as 1 = 'check failed'; its quality figures are
@@ -296,7 +300,9 @@ def test_fl_dsyev_vectors_passes_its_own_check_and_reports_it(n):
     dev = torch.device("cuda:0")
     wsb = FL.fl_dsyev_vectors_workspace_bytes(n)
     ws = torch.empty((wsb + 7) // 8, dtype=torch.float64, device=dev)
-    names = ("random", "projector", "near_clusters", "tiny", "hilbert") if n > 1024 else None
+    # (n >= 3072: the 1024-thread tridiagonalisation kernel with its own kept reflectors -- the device-side check looks at the
+    # tridiagonal's vectors only, so the final basis is held against A here: ADVICE r03)
+    names = (("random", "projector") if n >= 3072 else ("random", "projector", "near_clusters", "tiny", "hilbert")) if n > 1024 else None
     for name, A in _eig_cases(n, 500 + n).items():
         if names and name not in names:
             continue
@@ -306,9 +312,11 @@ def test_fl_dsyev_vectors_passes_its_own_check_and_reports_it(n):
         rc = FL.fl_dsyev_vectors(C.c_int(n), C.c_void_p(Ad.data_ptr()), C.c_int(n), C.c_void_p(w.data_ptr()),
                                  C.c_void_p(ws.data_ptr()), C.c_size_t(wsb), q, None)
         torch.cuda.synchronize()
-        if name in ("tiny", "huge"):
+        if name in ("tiny", "huge", "subnormal"):
             assert rc in (0, 1), (name, rc)
             continue
+        if n >= 3072 and name == "projector" and rc == 1:
+            continue  # (~2000-fold eigenvalues at this size: the fast path may give up -- it says so, the legacy symbol then runs Jacobi)
         assert rc == 0, (name, rc, list(q))
         assert q[0] <= 512 * 2.3e-16 and q[1] <= 512 * 2.3e-16 and q[2] in (1.0, 2.0, 3.0), (name, list(q))
         _check_basis(name, A, Ad.cpu().numpy().T, w.cpu().numpy(), n)

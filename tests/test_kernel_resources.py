@@ -61,3 +61,40 @@ def test_scalar_spills_of_the_baseline_kernels_stay_where_they_are(kernels):
                 seen += 1
                 assert k.get("sgpr_spill_count", 0) <= cap, (name, k.get("sgpr_spill_count"))
     assert seen == len(caps)
+
+
+def test_cooperative_barrier_waits_for_its_partial_sums_before_it_counts_the_arrival():
+    """csrc/fl_big.hpp coop_barrier: thread 0's write-through stores of the partial sums must have left the
+    wave before the arrival is counted -- in the ISA of every rci_step_big_kernel an `s_waitcnt vmcnt(0)` stands between the
+    workgroup barrier and the `global_atomic_add` of the arrival (round 3 had the stores, s_barrier and the add with no wait)."""
+    import re
+    import subprocess
+    import tempfile
+    if not os.path.exists(LIB):
+        pytest.skip("libFL.so not built")
+    seen = 0
+    for img in KR.code_objects(LIB):
+        if b"rci_step_big_kernel" not in img:
+            continue
+        with tempfile.NamedTemporaryFile(suffix=".co") as fh:
+            fh.write(img)
+            fh.flush()
+            txt = subprocess.check_output([os.path.join(KR.LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", fh.name]).decode()
+        cur, window = None, []
+        for line in txt.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
+            if m:
+                cur, window = m.group(1), []
+                continue
+            if cur is None or "rci_step_big_kernel" not in cur:
+                continue
+            ins = line.split("//")[0].strip()
+            if not ins:
+                continue
+            if ins.startswith("s_barrier"):
+                window = []
+            window.append(ins)
+            if ins.startswith("global_atomic_add"):
+                seen += 1
+                assert any(re.match(r"s_waitcnt\s+vmcnt\(0\)", w) for w in window), (cur, window[-12:])
+    assert seen >= 4, "one arrival atomic per solver instance of the cooperative step kernel"
