@@ -45,7 +45,18 @@ struct SolveArgs {
     int *outer;
     double *cnorm2;
     const void *user; // a caller-compiled objective's own data (include/fl_user_objective.hpp); not read by the built-in ones
+    // Staged launches of the augmented Lagrangian (fl_solver_kernels.hip: launch_aug_staged).  A problem may PAUSE at an outer
+    // iteration's boundary -- where the reference starts a fresh inner solve from (x, lambda, miu) anyway -- and be resumed by
+    // a later launch with more waves per problem; what a resumed problem needs beyond x and lambda is in pstate.
+    const int *list;    // this launch's problems (NULL: blockIdx.x); their number is sched[1]
+    int *sched;         // [0] problems finished so far (all launches), [1] problems listed for this launch
+    double *pstate;     // [batch][PSTATE]: miu, c.c, (outer, inner iterations, nf, ng as two doubles' worth of ints)
+    int pause_below;    // pause when at most this many problems of the batch are unfinished (0: never)
+    int resume;         // problems of this launch continue from pstate
+    int pause_grid;     // workgroups of a listed launch (an upper bound of sched[1])
 };
+#define FL_STATUS_PAUSED 3 // internal: never seen by a caller (every staged sequence ends with a launch that cannot pause)
+#define FL_PSTATE 4
 
 template <int NW, int EPT> struct Geo {
     static constexpr int T = NW * 64;
@@ -536,7 +547,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
     enum { GO_INIT_REST = -1, GO_DIRECTION = -2, GO_REFRESH = -3, GO_INIT_TAIL = -4, GO_DIRECTION_TAIL = -5 };
 
     __device__ __forceinline__ Solver(const SolveArgs &A_, double *lds_)
-        : A(A_), lds(lds_), prob(blockIdx.x), n(A_.n), R{lds_ + L_RED, 0}
+        : A(A_), lds(lds_), prob(A_.list ? A_.list[blockIdx.x] : (int)blockIdx.x), n(A_.n), R{lds_ + L_RED, 0}
     {
     }
 
@@ -671,6 +682,16 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
                 }
             }
             miu = A.miu0 > 1.0 ? A.miu0 : 1.0; // miu=max(1d0,miu0)
+            if (A.resume) { // continued from a paused launch: the outer loop's own state (x and lambda are in the caller's rows)
+                const double *ps = A.pstate + (size_t)prob * FL_PSTATE;
+                miu = uni(ps[0]);
+                cc = uni(ps[1]);
+                const int *pi = reinterpret_cast<const int *>(ps + 2);
+                outer_it = __builtin_amdgcn_readfirstlane(pi[0]);
+                inner_iters_total = __builtin_amdgcn_readfirstlane(pi[1]);
+                nf = __builtin_amdgcn_readfirstlane(pi[2]);
+                ng = __builtin_amdgcn_readfirstlane(pi[3]);
+            }
             const int tl = G::tid();
             if (tl < A.aug_m) lds[L_LAM + tl] = A.lambda[(size_t)prob * A.aug_m + tl];
             __syncthreads();
@@ -1636,6 +1657,15 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
                 phase = PH_DONE;
                 return 0;
             }
+            // staged launches: few problems are left running -- hand this one to the next launch, which gives it more waves
+            if (A.pause_below > 0) {
+                const int fin = __builtin_amdgcn_readfirstlane(__hip_atomic_load(A.sched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (A.batch - fin <= A.pause_below) {
+                    status = FL_STATUS_PAUSED;
+                    phase = PH_DONE;
+                    return 0;
+                }
+            }
             // fresh inner solve from the current x: every solver starts with an evaluation of L, L'
             recent = -1;
             lrec = -1;
@@ -2311,6 +2341,19 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
             __syncthreads();
             const int tl = G::tid();
             if (tl < A.aug_m) A.lambda[(size_t)prob * A.aug_m + tl] = lds[L_LAM + tl];
+        }
+        if constexpr (AUG) {
+            if (A.sched && G::ltid() == 0) {
+                if (status == FL_STATUS_PAUSED) {
+                    double *ps = A.pstate + (size_t)prob * FL_PSTATE;
+                    ps[0] = miu;
+                    ps[1] = cc;
+                    int *pi = reinterpret_cast<int *>(ps + 2);
+                    pi[0] = outer_it; pi[1] = inner_iters_total; pi[2] = nf; pi[3] = ng;
+                } else {
+                    __hip_atomic_fetch_add(A.sched, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
         if (G::ltid() == 0) {
             if (A.f_out) A.f_out[prob] = fnew;

@@ -133,15 +133,21 @@ static int device_compute_units()
 // runs the machine plus R - 1 helpers.  Only where that loop runs as a tight loop at all (Solver::spec_shrinking: augmented
 // Lagrangian around L-BFGS / CG, diagonal-quadratic or quartic objective, constraint blocks that are aligned lane groups) and
 // the geometry is one wave (128 < n <= 512).  Invisible in the results, so there is no option for it: by batch alone.
-// Measured on BASELINE config 5's family (ms; profiles/r04/geometry_by_batch.txt):
-//   batch      256   512  1024  1280  1536  2048  3072  4096  8192
-//   R = 1     63.2  64.1  72.5  73.4  73.2  75.7  80.6 103.5 140.9
-//   R = 2     42.0  50.5  54.7  55.5  60.5  63.3  85.9 104.2 178.9
-//   R = 4     29.9  35.9  50.4  54.8  68.1  74.0 108.1 137.5 252.8
-// FL_FORCE_REPLICAS in the environment overrides (tuning: tools/geometry_by_batch.py).
+// Measured on BASELINE config 5's family (ms; profiles/r04/geometry_by_batch.txt), R forced for the whole launch:
+//   batch      256   512  1024  1536  2048  3072  4096  8192
+//   R = 1     61.2  62.0  70.3  70.5  73.0  80.8 104.6 139.0
+//   R = 2     41.0  50.9  54.1  56.0  63.2  84.8 101.8 178.2
+//   R = 4     29.6  36.2  53.5  67.6  72.2 105.7 138.6 255.0
+//   shipped   29.7  36.2  41.5  49.7  54.3  58.1  68.9 113.5   <- R by batch for the START of the launch (below), then STAGED
+//                                                                 (solve(): the unfinished problems move to more waves)
+// FL_FORCE_REPLICAS in the environment overrides (tuning: tools/geometry_by_batch.py; it also switches the staging off).
 #ifndef FL_REP4_MAX_BATCH
-#define FL_REP4_MAX_BATCH 1280 // (problems per 256 CUs)
+#define FL_REP4_MAX_BATCH 512 // (problems per 256 CUs)
 #define FL_REP2_MAX_BATCH 2560
+#endif
+#ifndef FL_STAGE_T2
+#define FL_STAGE_T2 1536 // staged launches: problems left when the one-helper stage takes over ... (per 256 CUs)
+#define FL_STAGE_T4 512  // ... and the three-helper stage
 #endif
 // (fl_multi_solve runs several shards on one device at once: each of its threads says how many problems the device holds)
 static thread_local int tls_concurrent_batch = 0;
@@ -155,12 +161,19 @@ static int select_replicas(const GeoSel &g, int objective, int method, int n, in
     if (w != 32 && w != 64 && w != 128) return 1; // (Solver::init: cshift)
     if (const char *f = getenv("FL_FORCE_REPLICAS")) {
         const int r = atoi(f);
-        return (r == 2 || r == 4) ? r : 1;
+        return (r == 2 || r == 4 || r == 8) ? r : 1;
     }
     const long long scaled = (long long)batch * 256 / device_compute_units();
     if (scaled <= FL_REP4_MAX_BATCH) return 4;
     if (scaled <= FL_REP2_MAX_BATCH) return 2;
     return 1;
+}
+
+// the problems a staged launch left paused -> the next launch's list (order irrelevant: the problems are independent)
+__global__ void collect_paused_kernel(const int *status, int batch, int *list, int *sched)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < batch && status[k] == FL_STATUS_PAUSED) list[atomicAdd(sched + 1, 1)] = k;
 }
 
 #ifndef FL_ONLY_BENCH // the geometries are compiled in fl_solver_g*.hip
@@ -276,10 +289,64 @@ static int solve(int method, int objective, int batch, int n, double *x, const d
 #ifndef FL_ONLY_BENCH
     if (aug) {
         const int rep = select_replicas(g, objective, method, n, aug->m, batch);
-        if (rep > 1) {
-            const hipError_t er = g.ept == 8 ? launch_rep<1, 8>(rep, objective, method, A, st) : launch_rep<1, 4>(rep, objective, method, A, st);
-            return launch_status(er);
+        auto launch_with = [&](int r, const SolveArgs &B) {
+            if (r > 1) return g.ept == 8 ? launch_rep<1, 8>(r, objective, method, B, st) : launch_rep<1, 4>(r, objective, method, B, st);
+            return launch(g, objective, method, 1, B, st);
+        };
+        // Where helper waves exist for this kernel, a batch too large for them still ENDS as a small one: the evaluation counts
+        // of the problems differ 16-fold (BASELINE config 5: 8.5 k ... 150 k), so the last third of the launch is a tail of a
+        // few hundred long problems on a mostly idle chip.  STAGED: the launch picked by batch size (plain, or one helper wave)
+        // runs until at most FL_STAGE_T2 problems are unfinished; those pause at their next outer iteration's boundary -- where
+        // the reference starts a fresh inner solve from (x, lambda, miu) anyway, so resuming there changes no bit -- and a
+        // second launch continues them with one helper wave each, a third the last FL_STAGE_T4 with three.  Stream-ordered
+        // throughout: the lists are built on the device, a listed launch is sized for the most problems it can get and its
+        // surplus workgroups leave at once.  BASELINE config 5: 140 -> 112 ms; 4096 problems: 102 -> 70 ms (the thresholds sit
+        // on a flat optimum: profiles/r04/c5_staged.txt).  FL_AUG_STAGED=0 in the environment: one launch as before.
+        const bool eligible = select_replicas(g, objective, method, n, aug->m, 1) > 1 && !getenv("FL_FORCE_REPLICAS");
+        const char *stg = getenv("FL_AUG_STAGED");
+        const long long cus = device_compute_units();
+        int t2 = (int)((long long)FL_STAGE_T2 * cus / 256), t4 = (int)((long long)FL_STAGE_T4 * cus / 256);
+        if (const char *e2 = getenv("FL_STAGE_T2")) t2 = atoi(e2) > 0 ? atoi(e2) : t2; // (tuning: tools/stage_sweep.py)
+        if (const char *e4 = getenv("FL_STAGE_T4")) t4 = atoi(e4) > 0 && atoi(e4) <= t2 ? atoi(e4) : t4;
+        if (eligible && rep < 4 && batch > t4 && !(stg && stg[0] == '0') && status) {
+            // the stages: (waves per problem, pause when at most this many problems are left); the first one takes everybody
+            int stage_rep[3], stage_pause[3], ns = 0;
+            if (rep == 1 && batch > t2) { stage_rep[ns] = 1; stage_pause[ns++] = t2; }
+            if (rep <= 2) { stage_rep[ns] = ns ? 2 : rep; stage_pause[ns++] = t4; }
+            stage_rep[ns] = 4; stage_pause[ns++] = 0;
+            const int list_cap = stage_pause[0];
+            // scratch: [2] scheduler words | list [list_cap] | paused state [batch][FL_PSTATE] doubles
+            const size_t list_off = 16, ps_off = (list_off + (size_t)list_cap * sizeof(int) + 15) & ~(size_t)15;
+            const size_t bytes = ps_off + (size_t)batch * FL_PSTATE * sizeof(double);
+            char *scr = nullptr;
+            if (hipMallocAsync((void **)&scr, bytes, st) != hipSuccess) {
+                (void)hipGetLastError();
+                return launch_status(launch_with(rep, A)); // (no scratch: the single launch)
+            }
+            int *sched = reinterpret_cast<int *>(scr), *list = reinterpret_cast<int *>(scr + list_off);
+            SolveArgs B = A;
+            B.sched = sched;
+            B.pstate = reinterpret_cast<double *>(scr + ps_off);
+            hipError_t e = hipMemsetAsync(sched, 0, 16, st);
+            B.pause_below = stage_pause[0];
+            if (e == hipSuccess) e = launch_with(stage_rep[0], B);
+            for (int sgi = 1; sgi < ns && e == hipSuccess; ++sgi) {
+                e = hipMemsetAsync(sched + 1, 0, sizeof(int), st);
+                if (e != hipSuccess) break;
+                hipLaunchKernelGGL(collect_paused_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, status, batch, list, sched);
+                e = hipGetLastError();
+                if (e != hipSuccess) break;
+                B.list = list;
+                B.resume = 1;
+                B.pause_below = stage_pause[sgi];
+                B.pause_grid = stage_pause[sgi - 1]; // (at most that many paused)
+                e = launch_with(stage_rep[sgi], B);
+            }
+            const hipError_t ef = hipFreeAsync(scr, st);
+            if (e == hipSuccess) e = ef;
+            return launch_status(e);
         }
+        if (rep > 1) return launch_status(launch_with(rep, A));
     }
 #endif
     hipError_t e = launch(g, objective, method, aug != nullptr, A, st);

@@ -35,6 +35,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(min_wav
 void fl_solve_kernel(SolveArgs A)
 {
     using S = Solver<NW, EPT, OBJ, METHOD, AUG, EXACT>;
+    if constexpr (AUG) { // a listed launch (staged augmented Lagrangian) is sized for the most problems it can get
+        if (A.list && (int)blockIdx.x >= A.sched[1]) return;
+    }
 #ifndef FL_LDS_PAD // tuning knob: extra LDS per workgroup caps the workgroups resident per CU
 #define FL_LDS_PAD 0
 #endif
@@ -139,6 +142,7 @@ __global__ __launch_bounds__(REP * NW * 64) void fl_solve_rep_kernel(SolveArgs A
     constexpr int HL = (S::L_XS + 1) & ~1;      // a helper's: the machine's small arrays (lambda, c(x) buffers of its trials)
     constexpr int PUB = (S::PUB_DOUBLES + 2 + 1) & ~1; // what the master publishes per loop, then the command word
     __shared__ __attribute__((aligned(16))) double lds[LT + (REP - 1) * HL + PUB + 4 * SK * REP + REP + 2];
+    if (A.list && (int)blockIdx.x >= A.sched[1]) return; // (a listed launch is sized for the most problems it can get)
     const int rep = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     double *pub = lds + LT + (REP - 1) * HL, *xch = pub + PUB;
     volatile int *cmd = reinterpret_cast<volatile int *>(pub + S::PUB_DOUBLES);
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(REP * NW * 64) void fl_solve_rep_kernel(SolveArgs A
 template <int REP, int NW, int EPT, int OBJ, int METHOD>
 static hipError_t launch_rep_k(const SolveArgs &A, hipStream_t st)
 {
-    hipLaunchKernelGGL((fl_solve_rep_kernel<REP, NW, EPT, OBJ, METHOD, 1>), dim3(A.batch), dim3(REP * NW * 64), 0, st, A);
+    hipLaunchKernelGGL((fl_solve_rep_kernel<REP, NW, EPT, OBJ, METHOD, 1>), dim3(A.list ? A.pause_grid : A.batch), dim3(REP * NW * 64), 0, st, A);
     return hipGetLastError();
 }
 // (fl_solver_g*r.hip) objective: FL_OBJ_DIAGQUAD | FL_OBJ_QUARTIC, method: FL_SOLVER_LBFGS | FL_SOLVER_CG
@@ -262,6 +266,12 @@ static inline void fill_solve_args(SolveArgs &A, int method, int batch, int n, d
     A.outer = nullptr;
     A.cnorm2 = nullptr;
     A.user = nullptr;
+    A.list = nullptr;
+    A.sched = nullptr;
+    A.pstate = nullptr;
+    A.pause_below = 0;
+    A.resume = 0;
+    A.pause_grid = 0;
 #ifdef FL_PHASE_TIMERS
     if (const char *e = getenv("FL_PHASE_BUFFER")) A.user = (const void *)strtoull(e, nullptr, 16); // [batch][12] int64, device
 #endif
@@ -270,7 +280,7 @@ static inline void fill_solve_args(SolveArgs &A, int method, int batch, int n, d
 template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = 0>
 static hipError_t launch_k(const SolveArgs &A, hipStream_t st)
 {
-    hipLaunchKernelGGL((fl_solve_kernel<NW, EPT, OBJ, METHOD, AUG, EXACT>), dim3(A.batch), dim3(NW * 64), 0, st, A);
+    hipLaunchKernelGGL((fl_solve_kernel<NW, EPT, OBJ, METHOD, AUG, EXACT>), dim3(A.list ? A.pause_grid : A.batch), dim3(NW * 64), 0, st, A);
     return hipGetLastError();
 }
 template <int NW, int EPT, int OBJ> static hipError_t launch_m(int method, int aug, const SolveArgs &A, hipStream_t st)

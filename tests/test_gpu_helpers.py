@@ -133,3 +133,34 @@ def test_a_share_of_config5_runs_helped_and_equals_the_full_batch_rows(monkeypat
                        opts=O.defaults(precision=1e-10), sum_mode=O.TREE, threads=T, ept=E)
     assert np.array_equal(xs[:Q].cpu().numpy().view(np.uint64), o["x"].view(np.uint64))
     assert np.array_equal(os_["nf"][:Q].cpu().numpy(), o["nf"])
+
+
+def test_staged_launches_equal_the_single_launch(monkeypatch):
+    """BASELINE config 5 at full size (8192 x n = 512, M = 8): the library runs it STAGED -- the plain kernel until at most
+    2560 problems are unfinished, those pause at their next outer iteration's boundary and continue with one helper wave, the
+    last 1280 with three (csrc/fl_solver_kernels.hip).  Pausing there changes no bit (the reference starts a fresh inner solve
+    from (x, lambda, miu) at that point anyway, NO.f90:2155-2157): every output equals the single launch's (FL_AUG_STAGED=0),
+    no problem is left paused, and with nothing to pause (one outer iteration) the empty stages do no harm."""
+    NLO = _nlo()
+    monkeypatch.delenv("FL_FORCE_REPLICAS", raising=False)
+    n, M, B = 512, 8, 8192
+    dev = torch.device("cuda:0")
+    d = torch.empty(B, n, dtype=torch.float64, device=dev)
+    b = torch.empty_like(d)
+    x0 = torch.empty_like(d)
+    NLO.synth_diag_spectrum(20261003, d, 2.0, 10.0)
+    NLO.synth_uniform(20261003, b, -1.0, 1.0)
+    NLO.synth_uniform(20261010, x0, 0.05, 0.15)
+    for kw in ({"Precision": 1e-10}, {"Precision": 1e-10, "MaxIteration": 1}, {"Precision": 1e-10, "MaxIteration": 7}):
+        res = {}
+        for staged in ("1", "0"):
+            monkeypatch.setenv("FL_AUG_STAGED", staged)
+            x = x0.clone()
+            out = NLO.AugmentedLagrangian(NLO.DIAGQUAD, x, M, d, b, UnconstrainedSolver="LBFGS", **kw)
+            torch.cuda.synchronize()
+            res[staged] = (x, out)
+        assert torch.equal(res["1"][0], res["0"][0]), kw
+        for k in ("f", "nf", "ng", "iters", "outer", "lambda", "cnorm2", "status"):
+            assert torch.equal(res["1"][1][k], res["0"][1][k]), (kw, k)
+        assert int((res["1"][1]["status"] == 3).sum()) == 0
+    monkeypatch.delenv("FL_AUG_STAGED", raising=False)

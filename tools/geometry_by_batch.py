@@ -59,7 +59,7 @@ def workload(name, B):
         def run():
             x.copy_(x0)
             return NLO.AugmentedLagrangian(NLO.DIAGQUAD, x, M, d, b, UnconstrainedSolver="LBFGS", workspace_=ws, Precision=1e-10, Memory=m)
-        return run, ["1x8", "1x8r2", "1x8r4"]
+        return run, ["1x8", "1x8r2", "1x8r4", "auto"]
     if name in ("headline", "lbfgs512", "lbfgs256", "lbfgs2048"):
         n = {"headline": 1024, "lbfgs512": 512, "lbfgs256": 256, "lbfgs2048": 2048}[name]
         d, b = quad(B, n, 10.0, 1000.0)
@@ -104,8 +104,10 @@ def main():
             row = {"workload": name, "batch": B}
             for i, c in enumerate(cands):
                 # (the first one is the throughput geometry: not a latency candidate -> ignored; "r2" / "r4": replicated groups)
-                os.environ["FL_FORCE_GEOMETRY"] = c.split("r")[0]
-                os.environ["FL_FORCE_REPLICAS"] = c.split("r")[1] if "r" in c else "1"
+                if c == "auto":  # what the library does by itself (helper waves by batch, staged launches)
+                    os.environ.pop("FL_FORCE_REPLICAS", None)
+                else:
+                    os.environ["FL_FORCE_REPLICAS"] = c.split("r")[1] if "r" in c else "1"
                 out, ms = timed(run)
                 row[c] = round(ms, 3)
                 row[c + "_iters"] = int(out["iters"].to(torch.int64).sum())
