@@ -635,3 +635,68 @@ def multi_solve(solver, objective, x, d=None, b=None, M=0, lambda0=None, miu0=1.
                              p(out["gg"]), p(cn), p(out["iters"]), p(outer), p(out["status"]), p(out["nf"]), p(out["ng"]),
                              int(nshards), int(bool(interleaved))), "fl_multi_solve")
     return out
+
+
+# ---- YOUR objective inside the fused kernels, compiled at run time (fl_user_compile: hiprtc) -------------------------------
+FL.fl_user_compile.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+FL.fl_user_compile_check.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_size_t]
+FL.fl_user_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+FL.fl_user_solve.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _vp, C.POINTER(Options), _vp, C.c_size_t, _dp, _dp, _ip, _ip, _ip, _ip, _vp]
+FL.fl_user_destroy.argtypes = [C.c_void_p]
+TUNE_NONE = 4
+
+
+class CompiledObjective:
+    """An objective given as HIP source text -- the functor of include/fl_user_objective.hpp:
+        template <int NW, int EPT> struct Name { static constexpr int LDS_DOUBLES; init(A, prob, lds); eval(x, g, s0, s1, n, lds);
+        static combine(s0, s1); } --
+    compiled into the fused kernel of `solver` (SD | CG | LBFGS_ | BFGS_) for dimension n (<= 4096) by hiprtc; .solve() then
+    runs batches at the fused kernel's speed.  tune_like: DIAGQUAD for an element-wise objective keeping at most two data
+    vectors in registers, else TUNE_NONE.  The reference's interface for this is callbacks (NO.f90:33-38)."""
+
+    def __init__(self, source, class_name, n, solver=LBFGS_, tune_like=TUNE_NONE):
+        self.solver, self.n = int(solver), int(n)
+        h = C.c_void_p()
+        log = C.create_string_buffer(1 << 16)
+        rc = FL.fl_user_compile(C.byref(h), source.encode(), class_name.encode(), self.solver, self.n, int(tune_like), log, len(log))
+        self.log = log.value.decode(errors="replace")
+        if rc != OK:
+            raise FLError(f"fl_user_compile failed ({rc}):\n{self.log}")
+        self._h = h
+        t, e = C.c_int(), C.c_int()
+        FL.fl_user_geometry(self._h, C.byref(t), C.byref(e))
+        self.geometry = (t.value, e.value)
+
+    def solve(self, x, data0=None, data1=None, params=None, workspace_=None, options=None, **kw):
+        """x [batch, n] in/out; data0 / data1 [batch, n] and params (any CUDA tensor) reach the functor as A.d, A.b, A.user"""
+        import torch
+        B, n, out = _prep(x, data0, data1)
+        if n != self.n:
+            raise ValueError(f"compiled for n = {self.n}")
+        o = options if options is not None else default_options(self.solver, **kw)
+        ws = workspace_
+        nbytes = FL.fl_workspace_bytes_for(self.solver, B, n, C.byref(o))
+        if nbytes and (ws is None or ws.numel() * ws.element_size() < nbytes):
+            ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=x.device)
+        _check(FL.fl_user_solve(self._h, B, _ptr(x), _ptr(data0), _ptr(data1), _ptr(params), C.byref(o), _ptr(ws),
+                                ws.numel() * ws.element_size() if ws is not None else 0, _ptr(out["f"]), _ptr(out["gg"]),
+                                _ptr(out["iters"]), _ptr(out["status"]), _ptr(out["nf"]), _ptr(out["ng"]), _stream()), "fl_user_solve")
+        out["workspace"] = ws
+        return out
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h and FL is not None:  # (at interpreter exit the module's globals may be gone already)
+            FL.fl_user_destroy(h)
+            self._h = None
+
+
+def compile_objective(source, class_name, n, solver=LBFGS_, tune_like=TUNE_NONE):
+    return CompiledObjective(source, class_name, n, solver, tune_like)
+
+
+def compile_check(source, class_name, n, solver=LBFGS_, tune_like=TUNE_NONE, arch="gfx950"):
+    """compile only (no GPU needed): (return code, compiler log)"""
+    log = C.create_string_buffer(1 << 16)
+    rc = FL.fl_user_compile_check(source.encode(), class_name.encode(), int(solver), int(n), int(tune_like), arch.encode(), log, len(log))
+    return rc, log.value.decode(errors="replace")

@@ -421,6 +421,13 @@ template <int OBJ, int METHOD> struct BigSolver {
     {
         nf += (pending & FL_REQ_F) ? 1 : 0;
         ng += (pending & FL_REQ_G) ? 1 : 0;
+        if ((pending & FL_REQ_F) && fv != fv) { // (an objective that is not a number ends the problem: see Solver::advance)
+            status = FL_STATUS_NOT_FINITE;
+            fnew = fv;
+            phase = PH_DONE;
+            pending = 0;
+            return 0;
+        }
         int rq;
         if (phase == PH_INIT) {
             rq = after_init(fv, gg_new);

@@ -15,9 +15,15 @@
 // the request with a compiled-in objective and loop; the reverse-communication kernel
 // (fl_rci.hip) saves the machine to HBM and lets the caller evaluate.
 #pragma once
+#ifndef __HIPCC_RTC__ // (run-time compilation, csrc/fl_user_rtc.cpp: hiprtc brings the device runtime and the fixed-width types)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
+#if __has_include("fl_nlopt.h") // installed layout (prefix/include/fl/...) and run-time compilation: found on the include path
+#include "fl_nlopt.h"
+#else
 #include "../../include/fl_nlopt.h"
+#endif
 #include "fl_linesearch.hpp"
 #include "fl_reduce.hpp"
 
@@ -1298,6 +1304,18 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
     {
         nf += (pending & FL_REQ_F) ? 1 : 0;
         ng += (pending & FL_REQ_G) ? 1 : 0;
+        // An objective that is not a number ends the problem here (FL_STATUS_NOT_FINITE).  The reference's searchers compare
+        // their way out of every loop (zoom: NO.f90:1557-1579), so on NaN they -- and this restatement of them -- never leave:
+        // a host program that hangs is the caller's problem, a kernel that never ends takes the device with it.  No effect on
+        // any finite run (one comparison per request).
+        if ((pending & FL_REQ_F) && fv != fv) {
+            status = FL_STATUS_NOT_FINITE;
+            fnew = fv;
+            phase = PH_DONE;
+            pending = 0;
+            if constexpr (PRIO >= 1) __builtin_amdgcn_s_setprio(0);
+            return 0;
+        }
         int rq;
         if (phase == PH_INIT) {
             if constexpr (LAZY_GG) gg_new = reduce_gg();

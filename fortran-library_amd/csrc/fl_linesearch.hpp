@@ -23,7 +23,9 @@
 // with fx = fx0 (NO.f90:1507-1514) while the _fdwithf twin returns
 // (NO.f90:1628-1632).
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <math.h>
+#endif
 
 #if defined(__HIPCC__)
 #define FL_HD __host__ __device__ __forceinline__

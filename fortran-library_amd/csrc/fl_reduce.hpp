@@ -15,7 +15,9 @@
 // the same at the 16-lane step, so four values end up in the four rows of ONE register and share the four DPP
 // steps: 4 values cost 6 swaps + 8 DPP moves + 7 adds instead of 4 x (4 swaps + 8 moves + 6 adds).
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
+#endif
 
 namespace fl {
 

@@ -4,7 +4,9 @@
 // (one unit for all took six minutes); fl_solver_kernels.hip holds the dispatch by n and the C ABI.
 #pragma once
 #include "fl_device.hpp"
+#ifndef __HIPCC_RTC__ // (run-time compilation takes the kernels only: the host side of a launch is csrc/fl_user_rtc.cpp)
 #include "fl_host.hpp"
+#endif
 
 namespace fl {
 
@@ -204,6 +206,7 @@ __global__ __launch_bounds__(REP * NW * 64) void fl_solve_rep_kernel(SolveArgs A
     }
     if (master) s.finish();
 }
+#ifndef __HIPCC_RTC__ // ---- the host side of the launches (not part of a run-time compilation)
 template <int REP, int NW, int EPT, int OBJ, int METHOD>
 static hipError_t launch_rep_k(const SolveArgs &A, hipStream_t st)
 {
@@ -342,5 +345,6 @@ template <int NW, int EPT> hipError_t launch_newton(int obj, int aug, const Solv
     }
 #undef FL_NEWTON
 }
+#endif // __HIPCC_RTC__
 
 } // namespace fl

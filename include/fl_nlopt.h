@@ -31,8 +31,10 @@
  */
 #ifndef FL_NLOPT_H
 #define FL_NLOPT_H
+#ifndef __HIPCC_RTC__ /* (hiprtc brings its own) */
 #include <stddef.h>
 #include <stdint.h>
+#endif
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -54,6 +56,8 @@ extern "C" {
 #define FL_STATUS_CONVERGED 0      /* g.g < Precision^2                   (NO.f90:612)          */
 #define FL_STATUS_STEP_CONVERGED 1 /* p.p a^2 < MinStepLength^2 "step length has converged" (NO.f90:615) */
 #define FL_STATUS_MAXIT 2          /* MaxIteration exceeded              (NO.f90:580)           */
+#define FL_STATUS_NOT_FINITE 4     /* the objective returned NaN: the problem stops where it is (the reference's line      */
+                                   /* searchers would never return: their loops end on comparisons, NO.f90:1557-1579)      */
 #define FL_STATUS_NOT_SOLVED (-1)  /* fl_multi_solve only: the shard holding this problem failed (allocation, launch); */
                                    /* its rows of x and of the outputs are untouched                                  */
 
@@ -253,6 +257,41 @@ int fl_augmented_lagrangian_batched(int solver, int objective, int batch, int n,
                                     const fl_options *opt, void *workspace_dev, size_t workspace_bytes, double *f_dev,
                                     double *cnorm2_dev, int32_t *iters_dev, int32_t *outer_dev, int32_t *status_dev,
                                     int32_t *nf_dev, int32_t *ng_dev, void *stream);
+
+/* ---- YOUR objective inside the fused kernels, compiled at run time (csrc/fl_user_rtc.hip) ----------------------------
+ * The reference takes the objective as callbacks: subroutine f(fx,x,dim), fd(g,x,dim) (NO.f90:33-38).  A caller without hipcc
+ * in its build -- Python, Fortran, C -- passes the objective as HIP SOURCE TEXT: the functor of include/fl_user_objective.hpp
+ *     template <int NW, int EPT> struct <class_name> {
+ *         static constexpr int LDS_DOUBLES = ...;                       // doubles of LDS scratch eval() wants
+ *         __device__ void init(const fl::SolveArgs &A, int prob, double *lds);   // A.n, A.d, A.b, A.user: the data pointers
+ *         __device__ void eval(const double (&x)[EPT], double (&g)[EPT], double &s0, double &s1, int n, double *lds);
+ *         __device__ static double combine(double s0, double s1);       // f = combine(sum of s0, sum of s1)
+ *     };
+ * (layout of the thread's EPT elements and the helpers fl::load_user / fl::Geo: that header).  fl_user_compile builds
+ * fl_solve_kernel<geometry of n, FL_OBJ_USER, solver> around it with hiprtc -- about a second; the kernel's own headers are
+ * embedded in libFL.so, libhiprtc.so is opened on first use -- and fl_user_solve runs a batch with it: the fused kernel's
+ * speed (the reverse-communication form is 22 x slower on the headline workload), its geometry and summation order -- a
+ * functor restating a built-in objective reproduces it bit for bit.
+ *   solver     FL_SOLVER_SD | CG | LBFGS | BFGS (quasi-Newton updates: exact_step is taken as 0); n <= 4096
+ *   tune_like  whose register budget the kernel is tuned like: FL_OBJ_DIAGQUAD for an element-wise objective with at most two
+ *              data vectors in registers, FL_OBJ_USER_TUNE_NONE (4) when in doubt (no occupancy caps: nothing can spill)
+ *   log        (may be NULL) receives the compiler's messages, truncated to log_bytes
+ * Returns FL_OK; FL_ERR_INVALID_ARGUMENT: the source does not compile (see the log); FL_ERR_LAUNCH: no run-time compiler.
+ * fl_user_solve: x_dev [batch][n] in/out; data0_dev / data1_dev [batch][n] and params_dev arrive in the functor as A.d, A.b,
+ * A.user; options, workspace (fl_workspace_bytes_for) and outputs as fl_lbfgs_batched.  FL_RTC_CACHE_DIR in the environment:
+ * a directory where compiled code objects are kept between processes.
+ * fl_user_compile_check compiles only (no device needed; arch e.g. "gfx950"): for a build or CI step. */
+#define FL_OBJ_USER_TUNE_NONE 4
+typedef struct fl_user_objective fl_user_objective;
+int fl_user_compile(fl_user_objective **handle, const char *source, const char *class_name, int solver, int n, int tune_like,
+                    char *log, size_t log_bytes);
+int fl_user_compile_check(const char *source, const char *class_name, int solver, int n, int tune_like, const char *arch, char *log,
+                          size_t log_bytes);
+int fl_user_geometry(const fl_user_objective *handle, int *threads, int *ept);
+int fl_user_solve(fl_user_objective *handle, int batch, double *x_dev, const double *data0_dev, const double *data1_dev,
+                  const void *params_dev, const fl_options *opt, void *workspace_dev, size_t workspace_bytes, double *f_dev,
+                  double *gg_dev, int32_t *iters_dev, int32_t *status_dev, int32_t *nf_dev, int32_t *ng_dev, void *stream);
+int fl_user_destroy(fl_user_objective *handle);
 
 /* ---- all the GPUs of the node from one process --------------------------------------------------
  * The batched solvers above for HOST arrays, sharded over the visible devices by one host thread per shard (hipSetDevice,

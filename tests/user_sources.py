@@ -1,0 +1,96 @@
+"""Objectives written the way a CALLER writes them for the run-time compiled form (fl_user_compile, include/fl_nlopt.h): HIP
+source text of a functor with the interface of include/fl_user_objective.hpp.  Test material: each restates one of the
+library's built-in objectives, so the result can be held to the built-in kernel and to the oracle bit for bit."""
+
+# f = 1/2 sum d x^2 - sum b x  (element-wise; data0 = d, data1 = b, params = one double `half`: every term of the first sum
+# is shifted by half - 1/2 -- nothing at 0.5, a constant offset of f otherwise: shows that the parameter block arrives, with an
+# objective that stays finite and consistent with its gradient.  NEVER test with a NaN objective: the reference's zoom loop
+# does not terminate on NaN (NO.f90:1557-1579 compares its way out) and neither does its restatement -- a kernel that never ends)
+DIAGQUAD = r"""
+template <int NW, int EPT> struct MyQuadratic {
+    static constexpr int LDS_DOUBLES = 0;
+    double d[EPT], b[EPT], half;
+    __device__ void init(const fl::SolveArgs &A, int prob, double *)
+    {
+        fl::load_user<NW, EPT>(A.d + (size_t)prob * A.n, A.n, d);
+        fl::load_user<NW, EPT>(A.b + (size_t)prob * A.n, A.n, b);
+        half = A.user ? *static_cast<const double *>(A.user) : 0.5;
+    }
+    __device__ void eval(const double (&x)[EPT], double (&g)[EPT], double &s0, double &s1, int, double *)
+    {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const double dx = d[k] * x[k];
+            const double t0 = dx * x[k] + (half - 0.5), t1 = b[k] * x[k];
+            g[k] = dx - b[k];
+            s0 = (k == 0) ? t0 : s0 + t0;
+            s1 = (k == 0) ? t1 : s1 + t1;
+        }
+    }
+    __device__ static double combine(double s0, double s1) { return 0.5 * s0 - s1; }
+};
+"""
+
+# chained Rosenbrock f = sum_{i<n-1} 100 (x_{i+1} - x_i^2)^2 + (1 - x_i)^2: NEIGHBOUR-COUPLED -- every thread needs the
+# elements next to its 16-byte chunks, so x is staged through LDS (LDS_DOUBLES, two barriers per evaluation)
+ROSENBROCK = r"""
+template <int NW, int EPT> struct MyRosenbrock {
+    using G = fl::Geo<NW, EPT>;
+    static constexpr int LDS_DOUBLES = G::NPAD + 2;   // x with one halo element on each side
+    __device__ void init(const fl::SolveArgs &, int, double *xs)
+    {
+        if (G::ltid() == 0) {
+            xs[0] = 0.0;
+            xs[G::NPAD + 1] = 0.0;
+        }
+    }
+    __device__ void eval(const double (&x)[EPT], double (&g)[EPT], double &s0, double &s1, int n, double *xs)
+    {
+        s1 = 0.0;
+        __syncthreads();                               // the previous evaluation's neighbour reads are complete
+        for (int c = 0; c < G::NCH; ++c) {
+            const int e = G::e0(c);                    // the chunk's first element
+            xs[1 + e] = x[2 * c];
+            xs[2 + e] = x[2 * c + 1];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < G::NCH; ++c) {
+            const int e = G::e0(c);
+            const double xa = x[2 * c], xb = x[2 * c + 1];
+            const double xl = xs[e], xr = xs[e + 3];   // x[e-1], x[e+2]
+            const double ul = xa - xl * xl, ua = xb - xa * xa, ub = xr - xb * xb;
+            const double va = 1.0 - xa, vb = 1.0 - xb;
+            const double A_a = (e >= 1) ? 200.0 * ul : 0.0;
+            const double A_b = 200.0 * ua;
+            double ta = 0.0, tb = 0.0, ga = 0.0, gb = 0.0;
+            if (e <= n - 2) {
+                ta = 100.0 * (ua * ua) + va * va;
+                ga = A_a - 400.0 * xa * ua - 2.0 * va;
+            } else if (e == n - 1) {
+                ga = A_a;
+            }
+            if (e + 1 <= n - 2) {
+                tb = 100.0 * (ub * ub) + vb * vb;
+                gb = A_b - 400.0 * xb * ub - 2.0 * vb;
+            } else if (e + 1 == n - 1) {
+                gb = A_b;
+            }
+            g[2 * c] = ga;
+            g[2 * c + 1] = gb;
+            s0 = (c == 0) ? ta : s0 + ta;
+            s0 = s0 + tb;
+        }
+    }
+    __device__ static double combine(double s0, double) { return s0; }
+};
+"""
+
+BROKEN = r"""
+template <int NW, int EPT> struct Oops {
+    static constexpr int LDS_DOUBLES = 0;
+    __device__ void init(const fl::SolveArgs &, int, double *) {}
+    __device__ void eval(const double (&x)[EPT], double (&g)[EPT], double &s0, double &s1, int, double *) { s0 = undeclared_name; }
+    __device__ static double combine(double s0, double) { return s0; }
+};
+"""
