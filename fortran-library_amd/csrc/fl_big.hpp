@@ -417,17 +417,19 @@ template <int OBJ, int METHOD> struct BigSolver {
     }
 
     // ---------------------------------------------------------------- machine (Solver::advance and friends)
+    // (an objective that is not a number ends the problem: see Solver::not_finite)
+    __device__ __forceinline__ bool not_finite(double fv) const { return (pending & FL_REQ_F) && fv != fv; }
+    __device__ __forceinline__ void stop_not_finite()
+    {
+        status = FL_STATUS_NOT_FINITE;
+        fnew = __builtin_nan(""); // (not the value itself: it would have to stay in registers across advance())
+        phase = PH_DONE;
+        pending = 0;
+    }
     __device__ __forceinline__ int advance(double fv, double pv, double gg_new)
     {
         nf += (pending & FL_REQ_F) ? 1 : 0;
         ng += (pending & FL_REQ_G) ? 1 : 0;
-        if ((pending & FL_REQ_F) && fv != fv) { // (an objective that is not a number ends the problem: see Solver::advance)
-            status = FL_STATUS_NOT_FINITE;
-            fnew = fv;
-            phase = PH_DONE;
-            pending = 0;
-            return 0;
-        }
         int rq;
         if (phase == PH_INIT) {
             rq = after_init(fv, gg_new);

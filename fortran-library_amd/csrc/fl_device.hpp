@@ -420,6 +420,9 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
 #endif
     static constexpr int SPEC_K = (AUG && (OBJ == FL_OBJ_DIAGQUAD || OBJ == FL_OBJ_QUARTIC) && NW < 8 && FL_SPEC_K > 1) ? FL_SPEC_K : 1;
     static_assert(SPEC_K == 1 || SPEC_K == 2 || SPEC_K == 4, "1, 2 or 4 speculative trials");
+    // the kernels that take part in staged launches (pause at an outer iteration's boundary / resume: fl_solver_kernels.hip,
+    // launch_aug_staged) -- those that have helper-wave forms; the others do not carry the code
+    static constexpr bool STAGED = AUG && NW == 1 && SPEC_K > 1 && OBJ != FL_OBJ_EXTERNAL && (METHOD == FL_SOLVER_LBFGS || METHOD == FL_SOLVER_CG);
     static constexpr int L_CXS = L_CX + 2 * FL_MAX_CONSTRAINTS;  // c(x) of the speculative trials [2][SPEC_K][FL_MAX_CONSTRAINTS]
     // ... followed by one slot per thread that takes the stores of the lanes that own no block sum (evaluate_spec stores
     // from every lane, to a selected address: no exec-mask region splits the pass)
@@ -553,7 +556,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
     enum { GO_INIT_REST = -1, GO_DIRECTION = -2, GO_REFRESH = -3, GO_INIT_TAIL = -4, GO_DIRECTION_TAIL = -5 };
 
     __device__ __forceinline__ Solver(const SolveArgs &A_, double *lds_)
-        : A(A_), lds(lds_), prob(A_.list ? A_.list[blockIdx.x] : (int)blockIdx.x), n(A_.n), R{lds_ + L_RED, 0}
+        : A(A_), lds(lds_), prob((STAGED && A_.list) ? A_.list[blockIdx.x] : (int)blockIdx.x), n(A_.n), R{lds_ + L_RED, 0}
     {
     }
 
@@ -688,7 +691,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
                 }
             }
             miu = A.miu0 > 1.0 ? A.miu0 : 1.0; // miu=max(1d0,miu0)
-            if (A.resume) { // continued from a paused launch: the outer loop's own state (x and lambda are in the caller's rows)
+            if (STAGED && A.resume) { // continued from a paused launch: the outer loop's own state (x and lambda are in the caller's rows)
                 const double *ps = A.pstate + (size_t)prob * FL_PSTATE;
                 miu = uni(ps[0]);
                 cc = uni(ps[1]);
@@ -1304,18 +1307,6 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
     {
         nf += (pending & FL_REQ_F) ? 1 : 0;
         ng += (pending & FL_REQ_G) ? 1 : 0;
-        // An objective that is not a number ends the problem here (FL_STATUS_NOT_FINITE).  The reference's searchers compare
-        // their way out of every loop (zoom: NO.f90:1557-1579), so on NaN they -- and this restatement of them -- never leave:
-        // a host program that hangs is the caller's problem, a kernel that never ends takes the device with it.  No effect on
-        // any finite run (one comparison per request).
-        if ((pending & FL_REQ_F) && fv != fv) {
-            status = FL_STATUS_NOT_FINITE;
-            fnew = fv;
-            phase = PH_DONE;
-            pending = 0;
-            if constexpr (PRIO >= 1) __builtin_amdgcn_s_setprio(0);
-            return 0;
-        }
         int rq;
         if (phase == PH_INIT) {
             if constexpr (LAZY_GG) gg_new = reduce_gg();
@@ -1362,6 +1353,19 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
         return rq;
     }
     __device__ __forceinline__ double request_point() const { return ls.a_eval; }
+    // An objective that is not a number ends the problem (FL_STATUS_NOT_FINITE): called by the kernels' loops instead of
+    // advance().  The reference's searchers compare their way out of every loop (zoom: NO.f90:1557-1579), so on NaN they -- and
+    // this restatement of them -- never leave: a host program that hangs is the caller's problem, a kernel that never ends
+    // takes the device with it.  No effect on any finite run.  (In the loop, not inside advance(): an early return there cost
+    // the dense augmented-Lagrangian kernels 10-70 spilled VGPRs.)
+    __device__ __forceinline__ bool not_finite(double fv) const { return (pending & FL_REQ_F) && fv != fv; }
+    __device__ __forceinline__ void stop_not_finite()
+    {
+        status = FL_STATUS_NOT_FINITE;
+        fnew = __builtin_nan(""); // (not the value itself: it would have to stay in registers across advance())
+        phase = PH_DONE;
+        pending = 0;
+    }
 
     __device__ __forceinline__ int begin_linesearch()
     {
@@ -1676,7 +1680,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
                 return 0;
             }
             // staged launches: few problems are left running -- hand this one to the next launch, which gives it more waves
-            if (A.pause_below > 0) {
+            if (STAGED && A.pause_below > 0) {
                 const int fin = __builtin_amdgcn_readfirstlane(__hip_atomic_load(A.sched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 if (A.batch - fin <= A.pause_below) {
                     status = FL_STATUS_PAUSED;
@@ -2360,7 +2364,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
             const int tl = G::tid();
             if (tl < A.aug_m) A.lambda[(size_t)prob * A.aug_m + tl] = lds[L_LAM + tl];
         }
-        if constexpr (AUG) {
+        if constexpr (STAGED) {
             if (A.sched && G::ltid() == 0) {
                 if (status == FL_STATUS_PAUSED) {
                     double *ps = A.pstate + (size_t)prob * FL_PSTATE;

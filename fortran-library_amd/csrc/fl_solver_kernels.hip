@@ -35,6 +35,10 @@ template <int OBJ, int METHOD> __global__ __launch_bounds__(1024) void fl_big_so
             if (rq & FL_REQ_NOMOVE) s.evaluate(fv, pv, gg);
             else s.move_evaluate(s.request_point(), fv, pv, gg); // the trial point is formed and evaluated in one pass
         }
+        if (s.not_finite(fv)) { // (see Solver::not_finite)
+            s.stop_not_finite();
+            break;
+        }
         rq = s.advance(fv, pv, gg);
     }
     s.finish();

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(min_wav
 void fl_solve_kernel(SolveArgs A)
 {
     using S = Solver<NW, EPT, OBJ, METHOD, AUG, EXACT>;
-    if constexpr (AUG) { // a listed launch (staged augmented Lagrangian) is sized for the most problems it can get
+    if constexpr (S::STAGED) { // a listed launch (staged augmented Lagrangian) is sized for the most problems it can get
         if (A.list && (int)blockIdx.x >= A.sched[1]) return;
     }
 #ifndef FL_LDS_PAD // tuning knob: extra LDS per workgroup caps the workgroups resident per CU
@@ -106,7 +106,18 @@ void fl_solve_kernel(SolveArgs A)
 #ifdef FL_PHASE_TIMERS
             const int it0 = s.iters + s.inner_iters_total;
 #endif
+            // an objective that is not a number ends the problem (Solver::not_finite).  Written so that the loop keeps its one
+            // way out: a `break` here cost the dense BFGS kernel 130 more spilled SGPRs
+            // an objective that is not a number ends the problem (Solver::not_finite).  Tested BEFORE advance() -- which then
+            // takes one step of the machine with the NaN: a step has no loops -- and acted upon behind it, so that the loop keeps
+            // its one way out and no value stays live across advance() for it (a `break` before advance() cost the dense BFGS
+            // kernel 130 more spilled SGPRs, handing advance() a clean value the n <= 256 L-BFGS kernel 2 spilled VGPRs)
+            const bool nanv = s.not_finite(fv);
             rq = s.advance(fv, pv, gg);
+            if (nanv) {
+                s.stop_not_finite();
+                rq = 0;
+            }
 #ifdef FL_PHASE_TIMERS
             if (s.iters + s.inner_iters_total != it0) FL_T1(5); // a line search ended: convergence tests + the new direction
             else FL_T1(4);
@@ -201,7 +212,12 @@ __global__ __launch_bounds__(REP * NW * 64) void fl_solve_rep_kernel(SolveArgs A
                 s.template evaluate<true>(fv, pv, gg);
                 have_g = true;
             }
-            rq = s.advance(fv, pv, gg);
+            if (s.not_finite(fv)) { // (the objective is not a number: the problem ends here; the helpers are released below)
+                s.stop_not_finite();
+                rq = 0;
+            } else {
+                rq = s.advance(fv, pv, gg);
+            }
         }
     }
     if (master) s.finish();

@@ -56,8 +56,9 @@ extern "C" {
 #define FL_STATUS_CONVERGED 0      /* g.g < Precision^2                   (NO.f90:612)          */
 #define FL_STATUS_STEP_CONVERGED 1 /* p.p a^2 < MinStepLength^2 "step length has converged" (NO.f90:615) */
 #define FL_STATUS_MAXIT 2          /* MaxIteration exceeded              (NO.f90:580)           */
-#define FL_STATUS_NOT_FINITE 4     /* the objective returned NaN: the problem stops where it is (the reference's line      */
-                                   /* searchers would never return: their loops end on comparisons, NO.f90:1557-1579)      */
+#define FL_STATUS_NOT_FINITE 4     /* fused kernels: the objective returned NaN -- the problem stops where it is (the       */
+                                   /* reference's line searchers would never return: their loops end on comparisons,       */
+                                   /* NO.f90:1557-1579; by reverse communication the loop is the caller's)                 */
 #define FL_STATUS_NOT_SOLVED (-1)  /* fl_multi_solve only: the shard holding this problem failed (allocation, launch); */
                                    /* its rows of x and of the outputs are untouched                                  */
 
