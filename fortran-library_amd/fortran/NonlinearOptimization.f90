@@ -27,7 +27,8 @@ module NonlinearOptimization
     implicit none
 
     integer(c_int),parameter::FL_OBJ_QUARTIC=0,FL_OBJ_ROSENBROCK=1,FL_OBJ_DIAGQUAD=2
-    integer(c_int),parameter::FL_SOLVER_SD=0,FL_SOLVER_CG=1,FL_SOLVER_LBFGS=2,FL_SOLVER_BFGS=3
+    integer(c_int),parameter::FL_SOLVER_SD=0,FL_SOLVER_CG=1,FL_SOLVER_LBFGS=2,FL_SOLVER_BFGS=3,FL_SOLVER_NEWTON=4
+    integer(c_int),parameter::FL_REQ_F=1,FL_REQ_G=2,FL_REQ_SAME=4,FL_RCI_BOTH=1,FL_RCI_REQ_C=32,FL_RCI_REQ_CD=64
 
     type,bind(C)::fl_options!include/fl_nlopt.h: struct fl_options
         integer(c_int32_t)::strong,max_iteration
@@ -164,6 +165,108 @@ module NonlinearOptimization
             type(fl_options),intent(in)::opt
             real(c_double),value::miu0
         end function fl_multi_solve
+        !---- the other batched solvers on device-resident data (include/fl_nlopt.h; all pointers: device, c_null_ptr = absent)
+        integer(c_size_t) function fl_workspace_bytes_for(solver,batch,n,opt) bind(C,name='fl_workspace_bytes_for')
+            import
+            integer(c_int),value::solver,batch,n
+            type(fl_options),intent(in)::opt
+        end function fl_workspace_bytes_for
+        integer(c_int) function fl_steepest_descent_batched(objective,batch,n,x,d,b,opt,f,gg,iters,status,nf,ng,stream)&
+        bind(C,name='fl_steepest_descent_batched')
+            import
+            integer(c_int),value::objective,batch,n
+            type(c_ptr),value::x,d,b,f,gg,iters,status,nf,ng,stream
+            type(fl_options),intent(in)::opt
+        end function fl_steepest_descent_batched
+        integer(c_int) function fl_bfgs_batched(objective,batch,n,x,d,b,opt,ws,ws_bytes,f,gg,iters,status,nf,ng,stream)&
+        bind(C,name='fl_bfgs_batched')
+            import
+            integer(c_int),value::objective,batch,n
+            type(c_ptr),value::x,d,b,ws,f,gg,iters,status,nf,ng,stream
+            type(fl_options),intent(in)::opt
+            integer(c_size_t),value::ws_bytes
+        end function fl_bfgs_batched
+        integer(c_int) function fl_newton_raphson_batched(objective,batch,n,x,d,b,opt,ws,ws_bytes,f,gg,iters,status,nf,ng,stream)&
+        bind(C,name='fl_newton_raphson_batched')
+            import
+            integer(c_int),value::objective,batch,n
+            type(c_ptr),value::x,d,b,ws,f,gg,iters,status,nf,ng,stream
+            type(fl_options),intent(in)::opt
+            integer(c_size_t),value::ws_bytes
+        end function fl_newton_raphson_batched
+        integer(c_int) function fl_augmented_lagrangian_batched(solver,objective,batch,n,m,x,d,b,lambda,miu0,opt,ws,ws_bytes,f,&
+        cnorm2,iters,outer,status,nf,ng,stream) bind(C,name='fl_augmented_lagrangian_batched')
+            import
+            integer(c_int),value::solver,objective,batch,n,m
+            type(c_ptr),value::x,d,b,lambda,ws,f,cnorm2,iters,outer,status,nf,ng,stream
+            real(c_double),value::miu0
+            type(fl_options),intent(in)::opt
+            integer(c_size_t),value::ws_bytes
+        end function fl_augmented_lagrangian_batched
+        !---- reverse communication: the caller evaluates f, f' (and c, cd) for the batch between two steps -- the reference's
+        !callbacks f, fd, c, cd (NonlinearOptimization.f90:33-38, 1928-1934) as an ask / tell loop (include/fl_nlopt.h)
+        integer(c_int) function fl_rci_create(handle,solver,batch,n,opt,stream) bind(C,name='fl_rci_create')
+            import
+            type(c_ptr),intent(out)::handle
+            integer(c_int),value::solver,batch,n
+            type(fl_options),intent(in)::opt
+            type(c_ptr),value::stream
+        end function fl_rci_create
+        integer(c_int) function fl_rci_step(handle,x,f,g,request) bind(C,name='fl_rci_step')
+            import
+            type(c_ptr),value::handle,x,f,g,request
+        end function fl_rci_step
+        integer(c_int) function fl_rci_step_flags(handle,x,f,g,request,flags) bind(C,name='fl_rci_step_flags')
+            import
+            type(c_ptr),value::handle,x,f,g,request
+            integer(c_int),value::flags
+        end function fl_rci_step_flags
+        integer(c_int) function fl_rci_results(handle,f,gg,iters,status,nf,ng) bind(C,name='fl_rci_results')
+            import
+            type(c_ptr),value::handle,f,gg,iters,status,nf,ng
+        end function fl_rci_results
+        integer(c_int) function fl_rci_destroy(handle) bind(C,name='fl_rci_destroy')
+            import
+            type(c_ptr),value::handle
+        end function fl_rci_destroy
+        integer(c_int) function fl_rci_create_auglag(handle,solver,batch,n,m,lambda,miu0,opt,stream) bind(C,name='fl_rci_create_auglag')
+            import
+            type(c_ptr),intent(out)::handle
+            integer(c_int),value::solver,batch,n,m
+            type(c_ptr),value::lambda,stream
+            real(c_double),value::miu0
+            type(fl_options),intent(in)::opt
+        end function fl_rci_create_auglag
+        integer(c_int) function fl_rci_step_auglag(handle,x,f,g,c,cd,request) bind(C,name='fl_rci_step_auglag')
+            import
+            type(c_ptr),value::handle,x,f,g,c,cd,request
+        end function fl_rci_step_auglag
+        integer(c_int) function fl_rci_results_auglag(handle,cnorm2,outer) bind(C,name='fl_rci_results_auglag')
+            import
+            type(c_ptr),value::handle,cnorm2,outer
+        end function fl_rci_results_auglag
+        !---- the caller's objective as HIP source text, compiled into the fused kernel at run time (include/fl_nlopt.h):
+        !source and class_name are C strings (trim(text)//c_null_char); log receives the compiler's messages
+        integer(c_int) function fl_user_compile(handle,source,class_name,solver,n,tune_like,log,log_bytes) bind(C,name='fl_user_compile')
+            import
+            type(c_ptr),intent(out)::handle
+            character(kind=c_char),intent(in)::source(*),class_name(*)
+            integer(c_int),value::solver,n,tune_like
+            character(kind=c_char)::log(*)
+            integer(c_size_t),value::log_bytes
+        end function fl_user_compile
+        integer(c_int) function fl_user_solve(handle,batch,x,data0,data1,params,opt,ws,ws_bytes,f,gg,iters,status,nf,ng,stream)&
+        bind(C,name='fl_user_solve')
+            import
+            type(c_ptr),value::handle,x,data0,data1,params,ws,f,gg,iters,status,nf,ng,stream
+            integer(c_int),value::batch
+            type(fl_options),intent(in)::opt
+            integer(c_size_t),value::ws_bytes
+        end function fl_user_solve
+        integer(c_int) function fl_user_destroy(handle) bind(C,name='fl_user_destroy')
+            import
+            type(c_ptr),value::handle
+        end function fl_user_destroy
     end interface
 
 contains
@@ -507,5 +610,55 @@ contains
         info=fl_lbfgs_batched(objective,batch,dim,x_dev,d_dev,b_dev,o,ws_dev,ws_bytes,&
             f_dev,c_null_ptr,iters_dev,status_dev,c_null_ptr,c_null_ptr,c_null_ptr)
     end subroutine LBFGS_batched
+
+    !Batched augmented Lagrangian (reference AugmentedLagrangian, NonlinearOptimization.f90:2005-2241) on device-resident
+    !data: objective = built-in FL_OBJ_*, M block-sphere constraints, lambda_dev(M,batch) in (lambda0) / out; same keyword
+    !names as AugmentedLagrangian.  ws_dev: fl_workspace_bytes_for(inner solver, ...) bytes.
+    subroutine AugmentedLagrangian_batched(objective, x_dev, batch, N, M, d_dev, b_dev, lambda_dev, ws_dev, ws_bytes, &
+    f_dev, cnorm2_dev, iters_dev, outer_dev, status_dev, info, &
+    UnconstrainedSolver, miu0, ExactStep, Memory, Method, Strong, MaxIteration, Precision, MinStepLength, WolfeConst1, WolfeConst2, Increment)
+        integer,intent(in)::objective,batch,N,M
+        type(c_ptr),intent(in)::x_dev,d_dev,b_dev,lambda_dev,ws_dev,f_dev,cnorm2_dev,iters_dev,outer_dev,status_dev
+        integer(c_size_t),intent(in)::ws_bytes
+        integer,intent(out)::info
+        character*(*),intent(in),optional::UnconstrainedSolver,Method
+        real*8,intent(in),optional::miu0
+        integer,intent(in),optional::ExactStep,Memory,MaxIteration
+        logical,intent(in),optional::Strong
+        real*8,intent(in),optional::Precision,MinStepLength,WolfeConst1,WolfeConst2,Increment
+        type(fl_options)::o
+        integer(c_int)::solver
+        real(c_double)::mu
+        solver=FL_SOLVER_BFGS!the reference's default (NonlinearOptimization.f90:2074)
+        if(present(UnconstrainedSolver)) then
+            select case(UnconstrainedSolver)
+            case('NewtonRaphson'); solver=FL_SOLVER_NEWTON
+            case('BFGS'); solver=FL_SOLVER_BFGS
+            case('LBFGS'); solver=FL_SOLVER_LBFGS
+            case('ConjugateGradient'); solver=FL_SOLVER_CG
+            case default; stop 'Program abort: unsupported unconstrained solver'!NonlinearOptimization.f90:2186
+            end select
+        end if
+        call fl_default_options(o,solver)
+        if(present(Method)) then
+            select case(Method)
+            case('DY'); o%cg_method=0
+            case('PR'); o%cg_method=1
+            case default; stop 'Program abort: unsupported conjugate gradient method'
+            end select
+        end if
+        if(present(ExactStep)) o%exact_step=ExactStep
+        if(present(Memory)) o%memory=Memory
+        if(present(Strong)) o%strong=merge(1,0,Strong)
+        if(present(MaxIteration)) o%max_iteration=MaxIteration
+        if(present(Precision)) o%precision=Precision
+        if(present(MinStepLength)) o%min_step_length=MinStepLength
+        if(present(WolfeConst1)) o%wolfe_c1=WolfeConst1
+        if(present(WolfeConst2)) o%wolfe_c2=WolfeConst2
+        if(present(Increment)) o%increment=Increment
+        mu=1d0; if(present(miu0)) mu=miu0
+        info=fl_augmented_lagrangian_batched(solver,objective,batch,N,M,x_dev,d_dev,b_dev,lambda_dev,mu,o,ws_dev,ws_bytes,&
+            f_dev,cnorm2_dev,iters_dev,outer_dev,status_dev,c_null_ptr,c_null_ptr,c_null_ptr)
+    end subroutine AugmentedLagrangian_batched
 !------------------ End ------------------
 end module NonlinearOptimization

@@ -52,7 +52,11 @@
 #ifndef FL_USER_OBJECTIVE
 #error "define FL_USER_OBJECTIVE to your objective's class template before including fl_user_objective.hpp"
 #endif
+#if __has_include("fl/fl_solver_launch.hpp") // installed layout: prefix/include/fl/ (make install)
+#include "fl/fl_solver_launch.hpp"
+#else // the source tree
 #include "../fortran-library_amd/csrc/fl_solver_launch.hpp"
+#endif
 
 namespace fl {
 namespace user {

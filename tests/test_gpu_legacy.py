@@ -324,6 +324,23 @@ def test_fortran_use_fortranlibrary_smoke():
         assert v < (0.2 if k == "SD" else 1e-7 if k.startswith("AugLag") else 1.0 if k.endswith("f/f0") else 1e-3), (k, v)  # steepest descent on a quartic crawls; the rest reach ~1e-5
 
 
+def test_fortran_batched_entries_rci_loop_and_compiled_objective():
+    """tests/fortran/test_batched.f90: a Fortran program with a BATCH of problems -- AugmentedLagrangian_batched on device
+    memory (BASELINE config 5's shape) equal to fl_multi_solve bit for bit, a reverse-communication loop whose objective is
+    evaluated in Fortran on the host, and the objective handed over as HIP source text (fl_user_compile) equal to the
+    built-in one bit for bit.  The program checks itself and prints 'Mission complete'."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fortran-library_amd", "fortran", "test_batched")
+    if not os.path.exists(exe):
+        pytest.skip("Fortran batched test not built (make -C fortran-library_amd/fortran)")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Mission complete" in out.stdout and "FAILED" not in out.stdout, out.stdout
+    assert out.stdout.count("same bits") == 2 and " T" in out.stdout, out.stdout
+
+
 C_CB = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int))
 
 
