@@ -101,7 +101,7 @@ program main
     call chk(hipMemcpy(c_loc(xq),xd,nb,hipMemcpyDeviceToHost)); call chk(fl_rci_results(h,fd_,c_null_ptr,itd,std,c_null_ptr,c_null_ptr))
     call chk(hipMemcpy(c_loc(st),std,int(batch*4,c_size_t),hipMemcpyDeviceToHost)); call chk(fl_rci_destroy(h))
     write(*,'(A,I7,A,ES12.4)')' steps ',steps,'  max |x - b/d| ',maxval(abs(xq-b/d))
-    if(any(st/=0).or.maxval(abs(xq-b/d))>1d-7) then; write(*,*)'FAILED: reverse communication'; ok=.false.; end if
+    if(any(st>1).or.maxval(abs(xq-b/d))>1d-7) then; write(*,*)'FAILED: reverse communication'; ok=.false.; end if!(0 gradient / 1 step converged)
 
     write(*,*)'3. the objective as source text, compiled into the fused kernel at run time'
     src='template <int NW, int EPT> struct Quad {'//new_line('a')//&
