@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--rci-batch", type=int, default=16384)
     ap.add_argument("--coop-iterations", type=int, default=60)
     ap.add_argument("--rci-modes", default="legacy,full,compact")
+    ap.add_argument("--rci-fixed-shape", action="store_true", help="rci: the torch objective always reduces over the full [batch, n] buffers")
     args = ap.parse_args()
     global REPS
     REPS = args.reps
@@ -398,9 +399,21 @@ def main():
             dx = dd * xx
             return 0.5 * (dx * xx).sum(1) - (bb * xx).sum(1), dx - bb
 
+        xfull = torch.zeros(B, n, dtype=torch.float64, device=dev)
+
         def fun(xx, req=None, ids=None, epoch=None):
             calls["n"] += 1
             calls["rows"] += xx.shape[0]
+            if args.rci_fixed_shape:
+                # an objective whose row sums do NOT depend on how many rows the caller hands over: always evaluated on the full
+                # [B, n] buffers (torch picks its reduction strategy from the shape) -- attributes the 4-iteration difference of
+                # `compact` at the headline size to the caller's reduction or to the library
+                if ids is None:
+                    return f_of(xx, d, b)
+                i = ids.long()
+                xfull.index_copy_(0, i, xx)
+                ff, gg_ = f_of(xfull, d, b)
+                return ff[i], gg_[i]
             if ids is None:
                 return f_of(xx, d, b)
             if cache.get("epoch") != epoch:  # the list of running problems changed: gather their data once
@@ -420,7 +433,8 @@ def main():
             it = int(out["iters"].to(torch.int64).sum())
             if first is None:
                 first = (x.clone(), out["iters"].clone(), out["nf"].clone())
-            print(json.dumps({"config": f"RCI ({mode}) L-BFGS m=10, diagonal quadratics n=1024, batch {B}, torch objective", "ms": dt * 1e3,
+            print(json.dumps({"config": f"RCI ({mode}) L-BFGS m=10, diagonal quadratics n=1024, batch {B}, torch objective"
+                                        + (" evaluated on fixed-shape buffers" if args.rci_fixed_shape else ""), "ms": dt * 1e3,
                               "iterations_per_s": it / dt, "iterations": it, "steps": out["steps"], "objective_calls": calls["n"],
                               "objective_rows_evaluated": calls["rows"], "trials": int(out["nf"].to(torch.int64).sum()),
                               "rows_per_trial": calls["rows"] / max(1, int(out["nf"].to(torch.int64).sum())),
