@@ -880,10 +880,16 @@ def config_c5(ctx, NLO, prof, cpu_seconds):
                 "objective_evaluations_per_problem_min_mean_max": [float(nfp.min()), float(nfp.mean()), float(nfp.max())],
                 "converged_fraction_rank0": float((out["status"] == 0).double().mean()),
                 "constraint_norm_max_rank0": float(out["cnorm2"].max().sqrt()), "pmc_key": wl})
+    # how the library ran this rank's share (include/fl_nlopt.h: fl_augmented_lagrangian_launch_plan): helper waves by batch size
+    # for the start, the unfinished problems handed to launches with more waves per problem -- results do not depend on it
+    plan = NLO.augmented_lagrangian_launch_plan(NLO.LBFGS_, NLO.DIAGQUAD, B, n, M)
+    res["launch_plan"] = {"problems_on_this_rank": B, "stages": [{"waves_per_problem": w, "hands_over_when_unfinished_at_most": p} for w, p in plan],
+                          "note": "bit-identical to one launch of one wave per problem (tests/test_gpu_helpers.py)"}
     if ctx.world == 1:
-        res["roofline"] = valu_roofline(rec, stale, ms, "fl_solve_kernel<1,8,DIAGQUAD,LBFGS,AUG>")
-        res["roofline"]["note"] = ("one wave per problem, and the longest problem does ~5x the mean's objective evaluations: after the "
-                                   "first third of the launch most SIMDs hold fewer waves than they could (mean_waves_per_simd)")
+        res["roofline"] = valu_roofline(rec, stale, ms, "fl_solve_kernel<1,8,DIAGQUAD,LBFGS,AUG> + fl_solve_rep_kernel<2 / 4 waves> (the stages of one solve)")
+        res["roofline"]["note"] = ("the longest problem does ~5x the mean's objective evaluations; the plain kernel runs while the chip is "
+                                   "full of problems, the tail moves to launches with 2 and 4 waves per problem (launch_plan); counters = "
+                                   "the sum over the stages' kernels")
     if prof or cpu_seconds <= 0 or ctx.world > 1:
         return res
     import oracle_lib as O

@@ -643,6 +643,9 @@ FL.fl_user_compile_check.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C
 FL.fl_user_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
 FL.fl_user_solve.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _vp, C.POINTER(Options), _vp, C.c_size_t, _dp, _dp, _ip, _ip, _ip, _ip, _vp]
 FL.fl_user_destroy.argtypes = [C.c_void_p]
+FL.fl_user_compile_auglag.argtypes = FL.fl_user_compile.argtypes
+FL.fl_user_solve_auglag.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, _vp, _dp, C.c_double, C.POINTER(Options), _vp, C.c_size_t,
+                                    _dp, _dp, _ip, _ip, _ip, _ip, _ip, _vp]
 TUNE_NONE = 4
 
 
@@ -654,11 +657,12 @@ class CompiledObjective:
     runs batches at the fused kernel's speed.  tune_like: DIAGQUAD for an element-wise objective keeping at most two data
     vectors in registers, else TUNE_NONE.  The reference's interface for this is callbacks (NO.f90:33-38)."""
 
-    def __init__(self, source, class_name, n, solver=LBFGS_, tune_like=TUNE_NONE):
-        self.solver, self.n = int(solver), int(n)
+    def __init__(self, source, class_name, n, solver=LBFGS_, tune_like=TUNE_NONE, constrained=False):
+        self.solver, self.n, self.constrained = int(solver), int(n), bool(constrained)
         h = C.c_void_p()
         log = C.create_string_buffer(1 << 16)
-        rc = FL.fl_user_compile(C.byref(h), source.encode(), class_name.encode(), self.solver, self.n, int(tune_like), log, len(log))
+        comp = FL.fl_user_compile_auglag if constrained else FL.fl_user_compile
+        rc = comp(C.byref(h), source.encode(), class_name.encode(), self.solver, self.n, int(tune_like), log, len(log))
         self.log = log.value.decode(errors="replace")
         if rc != OK:
             raise FLError(f"fl_user_compile failed ({rc}):\n{self.log}")
@@ -684,6 +688,27 @@ class CompiledObjective:
         out["workspace"] = ws
         return out
 
+    def solve_auglag(self, x, M, data0=None, data1=None, params=None, lambda0=None, miu0=1.0, workspace_=None, options=None, **kw):
+        """AugmentedLagrangian around the compiled objective with M block-sphere constraints (compiled with constrained=True)"""
+        import torch
+        B, n, out = _prep(x, data0, data1)
+        o = options if options is not None else default_options(self.solver, **kw)
+        lam = torch.zeros(B, M, dtype=torch.float64, device=x.device) if lambda0 is None else lambda0.clone()
+        ws = workspace_
+        nbytes = FL.fl_workspace_bytes_for(self.solver, B, n, C.byref(o))
+        if nbytes and (ws is None or ws.numel() * ws.element_size() < nbytes):
+            ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=x.device)
+        out["cnorm2"] = torch.empty(B, dtype=torch.float64, device=x.device)
+        out["outer"] = torch.empty(B, dtype=torch.int32, device=x.device)
+        _check(FL.fl_user_solve_auglag(self._h, B, int(M), _ptr(x), _ptr(data0), _ptr(data1), _ptr(params), _ptr(lam), float(miu0), C.byref(o),
+                                       _ptr(ws), ws.numel() * ws.element_size() if ws is not None else 0, _ptr(out["f"]), _ptr(out["cnorm2"]),
+                                       _ptr(out["iters"]), _ptr(out["outer"]), _ptr(out["status"]), _ptr(out["nf"]), _ptr(out["ng"]), _stream()),
+               "fl_user_solve_auglag")
+        out["lambda"] = lam
+        out["workspace"] = ws
+        del out["gg"]
+        return out
+
     def __del__(self):
         h = getattr(self, "_h", None)
         if h and FL is not None:  # (at interpreter exit the module's globals may be gone already)
@@ -691,8 +716,8 @@ class CompiledObjective:
             self._h = None
 
 
-def compile_objective(source, class_name, n, solver=LBFGS_, tune_like=TUNE_NONE):
-    return CompiledObjective(source, class_name, n, solver, tune_like)
+def compile_objective(source, class_name, n, solver=LBFGS_, tune_like=TUNE_NONE, constrained=False):
+    return CompiledObjective(source, class_name, n, solver, tune_like, constrained)
 
 
 def compile_check(source, class_name, n, solver=LBFGS_, tune_like=TUNE_NONE, arch="gfx950"):
@@ -700,3 +725,16 @@ def compile_check(source, class_name, n, solver=LBFGS_, tune_like=TUNE_NONE, arc
     log = C.create_string_buffer(1 << 16)
     rc = FL.fl_user_compile_check(source.encode(), class_name.encode(), int(solver), int(n), int(tune_like), arch.encode(), log, len(log))
     return rc, log.value.decode(errors="replace")
+
+
+FL.fl_augmented_lagrangian_launch_plan.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
+
+
+def augmented_lagrangian_launch_plan(solver, objective, batch, n, M):
+    """[(waves per problem, hand over when at most this many problems are left; 0 = runs to the end), ...]: the launches
+    fl_augmented_lagrangian_batched makes for this batch on the current device (results do not depend on it)"""
+    w, p = (C.c_int * 3)(), (C.c_int * 3)()
+    ns = FL.fl_augmented_lagrangian_launch_plan(int(solver), int(objective), int(batch), int(n), int(M), w, p, 3)
+    if ns < 0:
+        _check(ns, "fl_augmented_lagrangian_launch_plan")
+    return [(w[k], p[k]) for k in range(ns)]

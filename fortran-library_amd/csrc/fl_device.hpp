@@ -391,7 +391,13 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
 #ifndef FL_BF_UNROLL
 #define FL_BF_UNROLL 4
 #endif
-    static constexpr int BF_UNROLL = FL_BF_UNROLL; // columns of H in flight per thread in the streaming passes
+    // columns of H in flight per thread in the streaming passes.  512-thread kernels (BASELINE config 4): two -- six interleaved
+    // repetitions each, profiles/r04/c4_unroll_ab.txt: 2 columns 370.4 ms, 4 columns 376.3, 8 columns 377.7 (round 3 had read the
+    // same 4 % / 2 % as noise from two repetitions)
+#ifndef FL_BF_UNROLL_W8
+#define FL_BF_UNROLL_W8 2
+#endif
+    static constexpr int BF_UNROLL = NW >= 8 ? FL_BF_UNROLL_W8 : FL_BF_UNROLL;
     static constexpr bool NEEDS_G0 = (METHOD != FL_SOLVER_SD && METHOD != FL_SOLVER_NEWTON);
     // LDS carve (doubles)
     static constexpr int L_RED = 0;                              // [2][NVMAX][NW]
@@ -418,7 +424,9 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
 #ifndef FL_SPEC_X0_RELOAD
 #define FL_SPEC_X0_RELOAD 0
 #endif
-    static constexpr int SPEC_K = (AUG && (OBJ == FL_OBJ_DIAGQUAD || OBJ == FL_OBJ_QUARTIC) && NW < 8 && FL_SPEC_K > 1) ? FL_SPEC_K : 1;
+    // (a caller's objective that declares itself element-wise -- tuned like the diagonal quadratic -- takes part too)
+    static constexpr int SPEC_K = (AUG && (OBJ == FL_OBJ_DIAGQUAD || OBJ == FL_OBJ_QUARTIC || (OBJ == FL_OBJ_USER && tuned_like<OBJ>() == FL_OBJ_DIAGQUAD)) &&
+                                   NW < 8 && FL_SPEC_K > 1) ? FL_SPEC_K : 1;
     static_assert(SPEC_K == 1 || SPEC_K == 2 || SPEC_K == 4, "1, 2 or 4 speculative trials");
     // the kernels that take part in staged launches (pause at an outer iteration's boundary / resume: fl_solver_kernels.hip,
     // launch_aug_staged) -- those that have helper-wave forms; the others do not carry the code

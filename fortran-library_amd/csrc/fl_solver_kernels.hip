@@ -216,6 +216,27 @@ static hipError_t launch(const GeoSel &g, int obj, int method, int aug, const So
 #endif
 }
 
+// The launches an augmented-Lagrangian solve of `batch` problems is made of: stage k runs `rep[k]` waves per problem and hands
+// the problems still unfinished when at most `pause[k]` are left (0: runs to the end) to stage k + 1.  One stage = one launch.
+static int aug_launch_plan(const GeoSel &g, int objective, int method, int n, int m, int batch, int (&rep)[3], int (&pause)[3])
+{
+    const int r0 = select_replicas(g, objective, method, n, m, batch);
+    rep[0] = r0;
+    pause[0] = 0;
+    const bool eligible = select_replicas(g, objective, method, n, m, 1) > 1 && !getenv("FL_FORCE_REPLICAS");
+    const char *stg = getenv("FL_AUG_STAGED");
+    const long long cus = device_compute_units();
+    int t2 = (int)((long long)FL_STAGE_T2 * cus / 256), t4 = (int)((long long)FL_STAGE_T4 * cus / 256);
+    if (const char *e2 = getenv("FL_STAGE_T2")) t2 = atoi(e2) > 0 ? atoi(e2) : t2; // (tuning: tools/stage_sweep.py)
+    if (const char *e4 = getenv("FL_STAGE_T4")) t4 = atoi(e4) > 0 && atoi(e4) <= t2 ? atoi(e4) : t4;
+    if (!eligible || r0 >= 4 || batch <= t4 || (stg && stg[0] == '0')) return 1;
+    int ns = 0;
+    if (r0 == 1 && batch > t2) { rep[ns] = 1; pause[ns++] = t2; }
+    rep[ns] = ns ? 2 : r0; pause[ns++] = t4;
+    rep[ns] = 4; pause[ns++] = 0;
+    return ns;
+}
+
 struct AugArgs {
     int m;
     double miu0;
@@ -306,18 +327,9 @@ static int solve(int method, int objective, int batch, int n, double *x, const d
         // throughout: the lists are built on the device, a listed launch is sized for the most problems it can get and its
         // surplus workgroups leave at once.  BASELINE config 5: 140 -> 112 ms; 4096 problems: 102 -> 70 ms (the thresholds sit
         // on a flat optimum: profiles/r04/c5_staged.txt).  FL_AUG_STAGED=0 in the environment: one launch as before.
-        const bool eligible = select_replicas(g, objective, method, n, aug->m, 1) > 1 && !getenv("FL_FORCE_REPLICAS");
-        const char *stg = getenv("FL_AUG_STAGED");
-        const long long cus = device_compute_units();
-        int t2 = (int)((long long)FL_STAGE_T2 * cus / 256), t4 = (int)((long long)FL_STAGE_T4 * cus / 256);
-        if (const char *e2 = getenv("FL_STAGE_T2")) t2 = atoi(e2) > 0 ? atoi(e2) : t2; // (tuning: tools/stage_sweep.py)
-        if (const char *e4 = getenv("FL_STAGE_T4")) t4 = atoi(e4) > 0 && atoi(e4) <= t2 ? atoi(e4) : t4;
-        if (eligible && rep < 4 && batch > t4 && !(stg && stg[0] == '0') && status) {
-            // the stages: (waves per problem, pause when at most this many problems are left); the first one takes everybody
-            int stage_rep[3], stage_pause[3], ns = 0;
-            if (rep == 1 && batch > t2) { stage_rep[ns] = 1; stage_pause[ns++] = t2; }
-            if (rep <= 2) { stage_rep[ns] = ns ? 2 : rep; stage_pause[ns++] = t4; }
-            stage_rep[ns] = 4; stage_pause[ns++] = 0;
+        int stage_rep[3], stage_pause[3];
+        const int ns = aug_launch_plan(g, objective, method, n, aug->m, batch, stage_rep, stage_pause);
+        if (ns > 1 && status) {
             const int list_cap = stage_pause[0];
             // scratch: [2] scheduler words | list [list_cap] | paused state [batch][FL_PSTATE] doubles
             const size_t list_off = 16, ps_off = (list_off + (size_t)list_cap * sizeof(int) + 15) & ~(size_t)15;
@@ -373,6 +385,19 @@ template <int NW, int EPT> static int onchip_pairs_o(int obj)
 extern "C" {
 
 int fl_version(void) { return 103; }
+
+int fl_augmented_lagrangian_launch_plan(int solver, int objective, int batch, int n, int m, int *waves, int *pause_below, int max_stages)
+{
+    fl::GeoSel g;
+    if (batch <= 0 || m <= 0 || !fl::select_fused_geometry(n, solver, true, g)) return FL_ERR_INVALID_ARGUMENT;
+    int rep[3], pause[3];
+    const int ns = fl::aug_launch_plan(g, objective, solver, n, m, batch, rep, pause);
+    for (int k = 0; k < ns && k < max_stages; ++k) {
+        if (waves) waves[k] = rep[k] * g.nw;
+        if (pause_below) pause_below[k] = pause[k];
+    }
+    return ns;
+}
 
 void fl_internal_set_concurrent_batch(int problems) { fl::tls_concurrent_batch = problems > 0 ? problems : 0; }
 

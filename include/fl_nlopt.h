@@ -259,6 +259,14 @@ int fl_augmented_lagrangian_batched(int solver, int objective, int batch, int n,
                                     double *cnorm2_dev, int32_t *iters_dev, int32_t *outer_dev, int32_t *status_dev,
                                     int32_t *nf_dev, int32_t *ng_dev, void *stream);
 
+/* How fl_augmented_lagrangian_batched will run `batch` problems on the current device (what bench.py reports next to its
+ * timings): the number of launches ("stages"), and per stage the waves per problem and the number of unfinished problems at
+ * which the stage hands over to the next one (0: runs to the end).  Where the kernel has helper-wave forms (L-BFGS / CG inside,
+ * diagonal-quadratic or quartic objective, 128 < n <= 512, block widths 32 / 64 / 128) a batch that under-fills the device
+ * starts with helper waves, and any batch ENDS with them: the unfinished problems pause at an outer iteration's boundary and
+ * continue in a launch with more waves per problem.  Results do not depend on the plan (bit-identical). */
+int fl_augmented_lagrangian_launch_plan(int solver, int objective, int batch, int n, int m, int *waves, int *pause_below, int max_stages);
+
 /* ---- YOUR objective inside the fused kernels, compiled at run time (csrc/fl_user_rtc.hip) ----------------------------
  * The reference takes the objective as callbacks: subroutine f(fx,x,dim), fd(g,x,dim) (NO.f90:33-38).  A caller without hipcc
  * in its build -- Python, Fortran, C -- passes the objective as HIP SOURCE TEXT: the functor of include/fl_user_objective.hpp
@@ -292,6 +300,17 @@ int fl_user_geometry(const fl_user_objective *handle, int *threads, int *ept);
 int fl_user_solve(fl_user_objective *handle, int batch, double *x_dev, const double *data0_dev, const double *data1_dev,
                   const void *params_dev, const fl_options *opt, void *workspace_dev, size_t workspace_bytes, double *f_dev,
                   double *gg_dev, int32_t *iters_dev, int32_t *status_dev, int32_t *nf_dev, int32_t *ng_dev, void *stream);
+/* AugmentedLagrangian (NO.f90:2005-2241) around the caller's objective with the library's constraint family (m block spheres,
+ * fl_augmented_lagrangian_batched): fl_user_compile_auglag builds the constrained kernel (solver: FL_SOLVER_LBFGS | FL_SOLVER_CG
+ * as the inner solver), fl_user_solve_auglag runs it; arguments as fl_augmented_lagrangian_batched.  An objective tuned like
+ * FL_OBJ_DIAGQUAD (element-wise) gets the tight objective-only loops of the line search too.  (Constraints of the caller's own:
+ * fl_rci_*_auglag.) */
+int fl_user_compile_auglag(fl_user_objective **handle, const char *source, const char *class_name, int solver, int n, int tune_like,
+                           char *log, size_t log_bytes);
+int fl_user_solve_auglag(fl_user_objective *handle, int batch, int m, double *x_dev, const double *data0_dev, const double *data1_dev,
+                         const void *params_dev, double *lambda_dev, double miu0, const fl_options *opt, void *workspace_dev,
+                         size_t workspace_bytes, double *f_dev, double *cnorm2_dev, int32_t *iters_dev, int32_t *outer_dev,
+                         int32_t *status_dev, int32_t *nf_dev, int32_t *ng_dev, void *stream);
 int fl_user_destroy(fl_user_objective *handle);
 
 /* ---- all the GPUs of the node from one process --------------------------------------------------

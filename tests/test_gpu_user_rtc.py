@@ -146,3 +146,32 @@ def test_an_objective_that_returns_nan_ends_the_problem_instead_of_hanging_the_k
     # (the iterates run into x > 0.25 somewhere on the way to b / d: every problem meets a NaN and stops there)
     assert bool((bad["status"] == 4).all()) and bool(torch.isnan(bad["f"]).all()), bad["status"]
     assert bool((bad["nf"] <= ok["nf"]).all())
+
+
+@pytest.mark.parametrize("inner,n,M", [("LBFGS", 512, 8), ("CG", 512, 8), ("LBFGS", 256, 4), ("LBFGS", 1024, 8), ("LBFGS", 200, 5)])
+def test_augmented_lagrangian_around_an_objective_given_as_source_equals_the_builtin(inner, n, M):
+    """fl_user_compile_auglag / fl_user_solve_auglag: the caller's objective (source text) inside the fused augmented-Lagrangian
+    kernel with the library's block-sphere constraints -- BASELINE config 5's shape and others; restating the diagonal quadratic
+    it equals fl_augmented_lagrangian_batched bit for bit (incl. the speculative objective-only trials: an element-wise
+    objective takes part in them)."""
+    NLO = _nlo()
+    dev = torch.device("cuda:0")
+    B = 6
+    rng = np.random.default_rng(n + M)
+    kappa = np.exp(rng.uniform(np.log(2), np.log(10), B))
+    d = 1.0 + (kappa[:, None] - 1.0) * (np.arange(n) / (n - 1))[None, :]
+    b = rng.uniform(-1, 1, (B, n))
+    x0 = 0.05 + 0.1 * rng.random((B, n))
+    dd, bb = torch.tensor(d, device=dev), torch.tensor(b, device=dev)
+    code = NLO.LBFGS_ if inner == "LBFGS" else NLO.CG
+    obj = NLO.compile_objective(US.DIAGQUAD, "MyQuadratic", n, solver=code, tune_like=NLO.DIAGQUAD, constrained=True)
+    xu = torch.tensor(x0, device=dev)
+    ou = obj.solve_auglag(xu, M, dd, bb, None, Precision=1e-8, MaxIteration=60)
+    xb = torch.tensor(x0, device=dev)
+    ob = NLO.AugmentedLagrangian(NLO.DIAGQUAD, xb, M, dd, bb, UnconstrainedSolver="LBFGS" if inner == "LBFGS" else "ConjugateGradient",
+                                 Precision=1e-8, MaxIteration=60)
+    torch.cuda.synchronize()
+    assert torch.equal(xu, xb)
+    for k in ("f", "cnorm2", "iters", "outer", "status", "nf", "ng", "lambda"):
+        assert torch.equal(ou[k], ob[k]), k
+    assert int(ou["nf"].min()) > 5 * int(ou["ng"].max()) // 4

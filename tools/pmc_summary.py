@@ -38,8 +38,12 @@ def kernel_stats(root):
     return out
 
 
+KERNELS_PER_STEP = 1  # --kernels-per-step K: a step is K dispatches of matching kernels (BASELINE config 5 staged: three)
+
+
 def counters(root, match):
-    """{counter: (sum per dispatch of kernels whose name contains `match`, dispatches, csv path)}"""
+    """{counter: (sum per STEP of kernels whose name contains `match`, dispatches, csv path)}; a step = KERNELS_PER_STEP
+    dispatches (1: per dispatch)"""
     res, info = {}, None
     passes = sorted(glob.glob(os.path.join(root, "pmc_*")))
     files = []
@@ -57,7 +61,7 @@ def counters(root, match):
                     "sgpr": r.get("SGPR_Count"), "lds": r.get("LDS_Block_Size"), "wg": r.get("Workgroup_Size"),
                     "grid": r.get("Grid_Size")}
         for name, v in acc.items():
-            res[name] = (v / max(1, len(nd)), len(nd), f)
+            res[name] = (v / max(1.0, len(nd) / float(KERNELS_PER_STEP)), len(nd), f)
     return res, info
 
 
@@ -66,6 +70,9 @@ def main():
     match = "solve_kernel"
     if "--match" in sys.argv:
         match = sys.argv[sys.argv.index("--match") + 1]
+    global KERNELS_PER_STEP
+    if "--kernels-per-step" in sys.argv:
+        KERNELS_PER_STEP = int(sys.argv[sys.argv.index("--kernels-per-step") + 1])
     ks = kernel_stats(root)
     for name, r in sorted(ks.items(), key=lambda kv: -kv[1]["total_ms"])[:12]:
         print(f"  {name[:90]:90s} calls {r['calls']:>4d} avg {r['avg_ms']:10.3f} ms  total {r['total_ms']:10.3f} ms  {r['pct']}%")
@@ -99,7 +106,8 @@ def main():
         if match in name:
             shutil.copy(r["file"], os.path.join(dst, f"{tag}_kernel_stats.csv"))
             src.append(f"profiles/{rnd}/{tag}_kernel_stats.csv")
-            kavg = r["avg_ms"]
+            # (several matching kernels = the stages of one step: their average durations add up)
+            kavg = r["avg_ms"] if (kavg is None or KERNELS_PER_STEP == 1) else kavg + r["avg_ms"]
     bj = os.path.join(root, "bench.json")  # the bench line of the kernel-trace pass (tools/profile.sh)
     b = json.loads([ln for ln in open(bj).read().splitlines() if ln.startswith("{")][-1])
     counters_kept = ("SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY",
