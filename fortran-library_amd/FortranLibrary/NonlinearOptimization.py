@@ -643,7 +643,7 @@ FL.fl_user_compile_check.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C
 FL.fl_user_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
 FL.fl_user_solve.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _vp, C.POINTER(Options), _vp, C.c_size_t, _dp, _dp, _ip, _ip, _ip, _ip, _vp]
 FL.fl_user_destroy.argtypes = [C.c_void_p]
-FL.fl_user_compile_auglag.argtypes = FL.fl_user_compile.argtypes
+FL.fl_user_compile_auglag.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
 FL.fl_user_solve_auglag.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, _vp, _dp, C.c_double, C.POINTER(Options), _vp, C.c_size_t,
                                     _dp, _dp, _ip, _ip, _ip, _ip, _ip, _vp]
 TUNE_NONE = 4
@@ -657,12 +657,17 @@ class CompiledObjective:
     runs batches at the fused kernel's speed.  tune_like: DIAGQUAD for an element-wise objective keeping at most two data
     vectors in registers, else TUNE_NONE.  The reference's interface for this is callbacks (NO.f90:33-38)."""
 
-    def __init__(self, source, class_name, n, solver=LBFGS_, tune_like=TUNE_NONE, constrained=False):
-        self.solver, self.n, self.constrained = int(solver), int(n), bool(constrained)
+    def __init__(self, source, class_name, n, solver=LBFGS_, tune_like=TUNE_NONE, constrained=False, constraints_class=None):
+        """constrained=True: inside the augmented Lagrangian; constraints_class: the caller's own constraints functor in the same
+        source (partial / add_gradient, include/fl_nlopt.h), else the library's block spheres"""
+        self.solver, self.n, self.constrained = int(solver), int(n), bool(constrained or constraints_class)
         h = C.c_void_p()
         log = C.create_string_buffer(1 << 16)
-        comp = FL.fl_user_compile_auglag if constrained else FL.fl_user_compile
-        rc = comp(C.byref(h), source.encode(), class_name.encode(), self.solver, self.n, int(tune_like), log, len(log))
+        if self.constrained:
+            rc = FL.fl_user_compile_auglag(C.byref(h), source.encode(), class_name.encode(), (constraints_class or "").encode(), self.solver,
+                                           self.n, int(tune_like), log, len(log))
+        else:
+            rc = FL.fl_user_compile(C.byref(h), source.encode(), class_name.encode(), self.solver, self.n, int(tune_like), log, len(log))
         self.log = log.value.decode(errors="replace")
         if rc != OK:
             raise FLError(f"fl_user_compile failed ({rc}):\n{self.log}")
@@ -716,8 +721,8 @@ class CompiledObjective:
             self._h = None
 
 
-def compile_objective(source, class_name, n, solver=LBFGS_, tune_like=TUNE_NONE, constrained=False):
-    return CompiledObjective(source, class_name, n, solver, tune_like, constrained)
+def compile_objective(source, class_name, n, solver=LBFGS_, tune_like=TUNE_NONE, constrained=False, constraints_class=None):
+    return CompiledObjective(source, class_name, n, solver, tune_like, constrained, constraints_class)
 
 
 def compile_check(source, class_name, n, solver=LBFGS_, tune_like=TUNE_NONE, arch="gfx950"):

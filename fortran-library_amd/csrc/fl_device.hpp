@@ -372,6 +372,35 @@ template <int NW, int EPT> struct Objective<FL_OBJ_USER, NW, EPT> : public FL_US
 #endif
 template <int OBJ> constexpr int tuned_like() { return OBJ == FL_OBJ_USER ? FL_USER_TUNE_LIKE : OBJ; }
 
+// CONSTRAINTS compiled in by the caller (AUG = FL_AUG_USER; include/fl_user_objective.hpp, fl_user_compile_auglag): the
+// reference's callbacks c(cx,x,M,N) and cd(cdx,x,M,N) (NO.f90:1928-1934) as a class template named by FL_USER_CONSTRAINTS
+//     template <int NW, int EPT> struct MyConstraints {
+//         __device__ void init(const fl::SolveArgs &A, int prob);      // A.aug_m = M (<= 8), A.user: the caller's data
+//         // the thread's share of every constraint: c_j(x) = (sum over all threads of cpart[j]) + offset(j)
+//         // (elements beyond n carry x = 0 and must contribute nothing; the constant of c_j -- e.g. -1 -- is offset(j),
+//         //  added AFTER the workgroup's sum)
+//         __device__ void partial(const double (&x)[EPT], double (&cpart)[8], int n);
+//         __device__ double offset(int j) const;
+//         // g[k] += sum_j v[j] * dc_j/dx_k for the thread's elements   (v = miu c - lambda: Ld, NO.f90:2205)
+//         __device__ void add_gradient(const double (&x)[EPT], const double (&v)[8], double (&g)[EPT], int n);
+//     };
+// The kernel sums cpart over the workgroup in its fixed order, in the same reduction as the objective's two sums.
+#define FL_AUG_USER 2
+#define FL_USER_MAX_CONSTRAINTS 8
+#ifdef FL_USER_CONSTRAINTS
+template <int NW, int EPT> struct UserConstraints : public FL_USER_CONSTRAINTS<NW, EPT> {};
+#else
+template <int NW, int EPT> struct UserConstraints { // (never used: no kernel with AUG = FL_AUG_USER is instantiated without the macro)
+    __device__ __forceinline__ void init(const SolveArgs &, int) {}
+    __device__ __forceinline__ void partial(const double (&)[EPT], double (&)[8], int) {}
+    __device__ __forceinline__ double offset(int) const { return 0.0; }
+    __device__ __forceinline__ void add_gradient(const double (&)[EPT], const double (&)[8], double (&)[EPT], int) {}
+};
+#endif
+struct NoConstraints {};
+template <bool B, class T, class F> struct pick_type { using type = T; }; // (std::conditional: not there under hiprtc)
+template <class T, class F> struct pick_type<false, T, F> { using type = F; };
+
 } // namespace fl
 #include "fl_dense.hpp"
 namespace fl {
@@ -425,7 +454,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
 #define FL_SPEC_X0_RELOAD 0
 #endif
     // (a caller's objective that declares itself element-wise -- tuned like the diagonal quadratic -- takes part too)
-    static constexpr int SPEC_K = (AUG && (OBJ == FL_OBJ_DIAGQUAD || OBJ == FL_OBJ_QUARTIC || (OBJ == FL_OBJ_USER && tuned_like<OBJ>() == FL_OBJ_DIAGQUAD)) &&
+    static constexpr int SPEC_K = (AUG == 1 && (OBJ == FL_OBJ_DIAGQUAD || OBJ == FL_OBJ_QUARTIC || (OBJ == FL_OBJ_USER && tuned_like<OBJ>() == FL_OBJ_DIAGQUAD)) &&
                                    NW < 8 && FL_SPEC_K > 1) ? FL_SPEC_K : 1;
     static_assert(SPEC_K == 1 || SPEC_K == 2 || SPEC_K == 4, "1, 2 or 4 speculative trials");
     // the kernels that take part in staged launches (pause at an outer iteration's boundary / resume: fl_solver_kernels.hip,
@@ -552,6 +581,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
         if constexpr (BLK_PER == 1) return blkp[k];
         else return (blkp[k >> 2] << (24 - 8 * (k & 3))) >> 24;
     }
+    typename pick_type<AUG == FL_AUG_USER, UserConstraints<NW, EPT>, NoConstraints>::type con; // the caller's constraints
     int cpar;               // which of the two c(x) buffers holds the last evaluation's constraints
     int spar;               // ... and which half of the speculative trials' buffers the last batch wrote
     int cshift;             // log2 of the lanes per constraint block where blocks are aligned lane groups (4, 5, 6), else 0
@@ -683,7 +713,8 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
         cpar = 0;
         if constexpr (SPEC_K > 1) spar = 0;
         if constexpr (AUG) {
-            if constexpr (OBJ != FL_OBJ_EXTERNAL) { // the built-in constraint family: block spheres
+            if constexpr (AUG == FL_AUG_USER) con.init(A, prob);
+            if constexpr (OBJ != FL_OBJ_EXTERNAL && AUG != FL_AUG_USER) { // the built-in constraint family: block spheres
                 const int w = n / A.aug_m;
                 if (w > 0 && (2 * G::T) % w == 0) cshift = (w == 128) ? 6 : (w == 64 ? 5 : (w == 32 ? 4 : 0));
                 if constexpr (BLK_PER > 1) {
@@ -748,7 +779,42 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
         } else {
             obj.eval(x, g, r[0], r[1], n, lds + L_XS);
         }
-        if constexpr (AUG) {
+        if constexpr (AUG == FL_AUG_USER) {
+            // the caller's constraints: the thread's shares of c_0 .. c_(m-1) and the objective's two sums in ONE reduction
+            const int m = A.aug_m;
+            double q[2 + FL_USER_MAX_CONSTRAINTS], cp[FL_USER_MAX_CONSTRAINTS];
+#pragma unroll
+            for (int u = 0; u < FL_USER_MAX_CONSTRAINTS; ++u) cp[u] = 0.0;
+            con.partial(x, cp, n);
+            q[0] = r[0];
+            q[1] = r[1];
+#pragma unroll
+            for (int u = 0; u < FL_USER_MAX_CONSTRAINTS; ++u) q[2 + u] = (u < m) ? cp[u] : 0.0;
+            if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(3);
+            __syncthreads(); // readers of the previous c(x) are done
+            double *cxs = cx_ptr();
+            R.run(q);
+            if (G::ltid() == 0) {
+#pragma unroll
+                for (int u = 0; u < FL_USER_MAX_CONSTRAINTS; ++u) cxs[u] = (u < m) ? q[2 + u] + con.offset(u) : 0.0;
+            }
+            __syncthreads();
+            double lc = 0.0, c2 = 0.0; // L = f - lambda.c + miu/2 c.c (NO.f90:2198)
+            for (int j = 0; j < m; ++j) {
+                lc = lc + lds[L_LAM + j] * cxs[j];
+                c2 = c2 + cxs[j] * cxs[j];
+            }
+            f = uni(Obj::combine(q[0], q[1]) - lc + miu / 2.0 * c2);
+            if constexpr (!WANT_G) return;
+            double v[FL_USER_MAX_CONSTRAINTS]; // Ldx=Ldx+matmul(cdx,miu*cx-lambda) (NO.f90:2205)
+#pragma unroll
+            for (int j = 0; j < FL_USER_MAX_CONSTRAINTS; ++j) v[j] = (j < m) ? miu * cxs[j] - lds[L_LAM + j] : 0.0;
+            con.add_gradient(x, v, g, n);
+            double q2[2] = {dot_part<EPT>(g, p), dot_part<EPT>(g, g)};
+            R.run(q2);
+            gp = uni(q2[0]);
+            ggo = uni(q2[1]);
+        } else if constexpr (AUG) {
             // c_j: masked full-width sums of x^2 (one reduction of aug_m values with the objective's)
             const int m = A.aug_m;
             // the thread's share of c_j + 1: its elements of block j squared, summed in element order (only the

@@ -22,6 +22,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG> constexpr int min_waves
     return FL_MIN_WPE;
 #else
     // (the quartic / Rosenbrock instances would spill 10-14 VGPRs under the cap: left alone)
+    if (AUG == FL_AUG_USER) return 1; // (the caller's constraints: no occupancy caps -- nothing can spill for them)
     if (AUG && EPT == 4 && NW <= 2 && tuned_like<OBJ>() == FL_OBJ_DIAGQUAD && (METHOD == FL_SOLVER_LBFGS || METHOD == FL_SOLVER_CG)) return 4;
     if (FL_AUG_LEAN18 && AUG && EPT == 8 && NW == 1 && tuned_like<OBJ>() == FL_OBJ_DIAGQUAD && (METHOD == FL_SOLVER_LBFGS || METHOD == FL_SOLVER_CG)) return FL_AUG18_WPE; // Solver::AUG_LEAN18 (4 waves: 80-100 spills)
     // SD / CG on them at 8 elements per thread, x0 in LDS (Solver::X0_LDS)

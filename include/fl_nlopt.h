@@ -300,13 +300,22 @@ int fl_user_geometry(const fl_user_objective *handle, int *threads, int *ept);
 int fl_user_solve(fl_user_objective *handle, int batch, double *x_dev, const double *data0_dev, const double *data1_dev,
                   const void *params_dev, const fl_options *opt, void *workspace_dev, size_t workspace_bytes, double *f_dev,
                   double *gg_dev, int32_t *iters_dev, int32_t *status_dev, int32_t *nf_dev, int32_t *ng_dev, void *stream);
-/* AugmentedLagrangian (NO.f90:2005-2241) around the caller's objective with the library's constraint family (m block spheres,
- * fl_augmented_lagrangian_batched): fl_user_compile_auglag builds the constrained kernel (solver: FL_SOLVER_LBFGS | FL_SOLVER_CG
- * as the inner solver), fl_user_solve_auglag runs it; arguments as fl_augmented_lagrangian_batched.  An objective tuned like
- * FL_OBJ_DIAGQUAD (element-wise) gets the tight objective-only loops of the line search too.  (Constraints of the caller's own:
- * fl_rci_*_auglag.) */
-int fl_user_compile_auglag(fl_user_objective **handle, const char *source, const char *class_name, int solver, int n, int tune_like,
-                           char *log, size_t log_bytes);
+/* AugmentedLagrangian (NO.f90:2005-2241) around the caller's objective -- and, where constraints_class_name is given, the caller's
+ * CONSTRAINTS: the reference's callbacks c(cx,x,M,N), cd(cdx,x,M,N) (NO.f90:1928-1934) as a second class template in the same source
+ *     template <int NW, int EPT> struct <constraints_class_name> {
+ *         __device__ void init(const fl::SolveArgs &A, int prob);                              // A.aug_m = M (<= 8), A.user
+ *         __device__ void partial(const double (&x)[EPT], double (&cpart)[8], int n);           // c_j(x) = sum over threads of cpart[j] + offset(j)
+ *         __device__ double offset(int j) const;                                                // the constant of c_j (added after the sum)
+ *         __device__ void add_gradient(const double (&x)[EPT], const double (&v)[8], double (&g)[EPT], int n);  // g += sum_j v_j grad c_j
+ *     };
+ * (csrc/fl_device.hpp, FL_USER_CONSTRAINTS).  constraints_class_name NULL or "": the library's constraint family (m block
+ * spheres, fl_augmented_lagrangian_batched; an objective tuned like FL_OBJ_DIAGQUAD then gets the tight objective-only loops of the
+ * line search too).  solver: FL_SOLVER_LBFGS | FL_SOLVER_CG as the inner solver.  fl_user_solve_auglag: arguments as
+ * fl_augmented_lagrangian_batched (m <= 8 with the caller's constraints). */
+int fl_user_compile_auglag(fl_user_objective **handle, const char *source, const char *class_name, const char *constraints_class_name,
+                           int solver, int n, int tune_like, char *log, size_t log_bytes);
+int fl_user_compile_check_auglag(const char *source, const char *class_name, const char *constraints_class_name, int solver, int n,
+                                 int tune_like, const char *arch, char *log, size_t log_bytes); /* compiles only, no device */
 int fl_user_solve_auglag(fl_user_objective *handle, int batch, int m, double *x_dev, const double *data0_dev, const double *data1_dev,
                          const void *params_dev, double *lambda_dev, double miu0, const fl_options *opt, void *workspace_dev,
                          size_t workspace_bytes, double *f_dev, double *cnorm2_dev, int32_t *iters_dev, int32_t *outer_dev,

@@ -96,5 +96,42 @@ int solve(int solver, int batch, int n, double *x_dev, const double *data0_dev, 
     return launch_status(e);
 }
 
+// AugmentedLagrangian (NO.f90:2005-2241) around the objective: with FL_USER_CONSTRAINTS defined (a class template with init /
+// partial / add_gradient, csrc/fl_device.hpp) the caller's own constraints, m <= 8; without it the library's m block spheres.
+// solver: FL_SOLVER_LBFGS | FL_SOLVER_CG (the inner solver); arguments as fl_augmented_lagrangian_batched.
+template <int NW, int EPT>
+int solve_auglag(int solver, int batch, int n, int m, double *x_dev, const double *data0_dev, const double *data1_dev, const void *params_dev,
+                 double *lambda_dev, double miu0, const fl_options *opt, void *workspace_dev, size_t workspace_bytes, double *f_dev,
+                 double *cnorm2_dev, int32_t *iters_dev, int32_t *outer_dev, int32_t *status_dev, int32_t *nf_dev, int32_t *ng_dev,
+                 hipStream_t stream)
+{
+#ifdef FL_USER_CONSTRAINTS
+    constexpr int A_ = FL_AUG_USER;
+    if (m < 1 || m > FL_USER_MAX_CONSTRAINTS) return FL_ERR_INVALID_ARGUMENT;
+#else
+    constexpr int A_ = 1;
+    if (m < 1 || m > FL_MAX_CONSTRAINTS || n % m != 0) return FL_ERR_INVALID_ARGUMENT;
+#endif
+    if (!x_dev || !opt || !lambda_dev || batch <= 0 || n <= 0) return FL_ERR_INVALID_ARGUMENT;
+    if (solver != FL_SOLVER_CG && solver != FL_SOLVER_LBFGS) return FL_ERR_INVALID_ARGUMENT;
+    int threads = 0, ept = 0;
+    if (fl_reduction_geometry(n, &threads, &ept) != FL_OK || n > 4096) return FL_ERR_UNSUPPORTED_SIZE;
+    if (threads != NW * 64 || ept != EPT) return FL_ERR_INVALID_ARGUMENT; // not the geometry of this n
+    if (solver == FL_SOLVER_LBFGS && (!workspace_dev || workspace_bytes < fl_workspace_bytes_for(solver, batch, n, opt))) return FL_ERR_WORKSPACE;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FL_ERR_NO_DEVICE;
+    SolveArgs A;
+    fill_solve_args(A, solver, batch, n, x_dev, data0_dev, data1_dev, opt, workspace_dev, f_dev, nullptr, iters_dev, status_dev, nf_dev, ng_dev);
+    A.user = params_dev;
+    A.aug_m = m;
+    A.miu0 = miu0;
+    A.lambda = lambda_dev;
+    A.outer = outer_dev;
+    A.cnorm2 = cnorm2_dev;
+    const hipError_t e = solver == FL_SOLVER_CG ? launch_k<NW, EPT, FL_OBJ_USER, FL_SOLVER_CG, A_>(A, stream)
+                                                : launch_k<NW, EPT, FL_OBJ_USER, FL_SOLVER_LBFGS, A_>(A, stream);
+    return launch_status(e);
+}
+
 } // namespace user
 } // namespace fl

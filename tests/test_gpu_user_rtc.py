@@ -175,3 +175,61 @@ def test_augmented_lagrangian_around_an_objective_given_as_source_equals_the_bui
     for k in ("f", "cnorm2", "iters", "outer", "status", "nf", "ng", "lambda"):
         assert torch.equal(ou[k], ob[k]), k
     assert int(ou["nf"].min()) > 5 * int(ou["ng"].max()) // 4
+
+
+@pytest.mark.parametrize("inner,n,M", [("LBFGS", 512, 8), ("CG", 512, 8), ("LBFGS", 256, 4), ("LBFGS", 1024, 8), ("LBFGS", 300, 5)])
+def test_constraints_given_as_source_equal_the_builtin_family_and_the_oracle(inner, n, M):
+    """the reference's c, cd callbacks (NO.f90:1928-1934) as a constraints FUNCTOR in the caller's source: block spheres restated
+    by the caller = fl_augmented_lagrangian_batched = the oracle, bit for bit (the caller's constraints go through one masked
+    reduction, the built-in ones through lane-group sums and speculative trials: same bits by construction)."""
+    NLO = _nlo()
+    dev = torch.device("cuda:0")
+    B = 5
+    rng = np.random.default_rng(n * M)
+    kappa = np.exp(rng.uniform(np.log(2), np.log(10), B))
+    d = 1.0 + (kappa[:, None] - 1.0) * (np.arange(n) / (n - 1))[None, :]
+    b = rng.uniform(-1, 1, (B, n))
+    x0 = 0.05 + 0.1 * rng.random((B, n))
+    dd, bb = torch.tensor(d, device=dev), torch.tensor(b, device=dev)
+    code = NLO.LBFGS_ if inner == "LBFGS" else NLO.CG
+    obj = NLO.compile_objective(US.DIAGQUAD + US.BLOCK_SPHERES, "MyQuadratic", n, solver=code, tune_like=NLO.DIAGQUAD, constraints_class="MySpheres")
+    xu = torch.tensor(x0, device=dev)
+    ou = obj.solve_auglag(xu, M, dd, bb, None, Precision=1e-8, MaxIteration=60)
+    xb = torch.tensor(x0, device=dev)
+    ob = NLO.AugmentedLagrangian(NLO.DIAGQUAD, xb, M, dd, bb, UnconstrainedSolver="LBFGS" if inner == "LBFGS" else "ConjugateGradient",
+                                 Precision=1e-8, MaxIteration=60)
+    torch.cuda.synchronize()
+    assert torch.equal(xu, xb)
+    for k in ("f", "cnorm2", "iters", "outer", "status", "nf", "ng", "lambda"):
+        assert torch.equal(ou[k], ob[k]), k
+    T, E = NLO.reduction_geometry(n)
+    o = O.auglag_batch(O.LBFGS if inner == "LBFGS" else O.CG, O.DIAGQUAD, x0, M, d=d, b=b,
+                       opts=O.defaults(precision=1e-8, maxit=60, c2=0.45 if inner != "LBFGS" else 0.9), sum_mode=O.TREE, threads=T, ept=E)
+    assert np.array_equal(xu.cpu().numpy().view(np.uint64), o["x"].view(np.uint64)) and np.array_equal(ou["nf"].cpu().numpy(), o["nf"])
+
+
+@pytest.mark.parametrize("n,M", [(512, 8), (1000, 3), (130, 1)])
+def test_linear_constraints_given_as_source_reach_the_kkt_point(n, M):
+    """a family the library does not have: c_j = sum_{i = j mod M} x_i - 1.  For f = 1/2 sum d x^2 - sum b x the constrained
+    minimiser is x_i = (b_i + nu_j) / d_i with nu_j = (1 - sum_{S_j} b/d) / sum_{S_j} 1/d: the augmented Lagrangian around the
+    compiled objective + constraints lands on it (||c|| < Precision, x within 1e-8, multipliers = -nu)."""
+    NLO = _nlo()
+    dev = torch.device("cuda:0")
+    B = 7
+    rng = np.random.default_rng(n + M)
+    d = 1.0 + 4.0 * rng.random((B, n))
+    b = rng.uniform(-1, 1, (B, n))
+    obj = NLO.compile_objective(US.DIAGQUAD + US.STRIDE_SUMS, "MyQuadratic", n, solver=NLO.LBFGS_, tune_like=NLO.DIAGQUAD, constraints_class="MyStrideSums")
+    x = torch.zeros(B, n, dtype=torch.float64, device=dev)
+    out = obj.solve_auglag(x, M, torch.tensor(d, device=dev), torch.tensor(b, device=dev), None, Precision=1e-10, MaxIteration=200)
+    torch.cuda.synchronize()
+    xs = np.empty((B, n))
+    nu = np.empty((B, M))
+    for j in range(M):
+        S = np.arange(j, n, M)
+        nu[:, j] = (1.0 - (b[:, S] / d[:, S]).sum(1)) / (1.0 / d[:, S]).sum(1)
+        xs[:, S] = (b[:, S] + nu[:, j][:, None]) / d[:, S]
+    assert bool((out["status"] == 0).all()) and float(out["cnorm2"].max()) < 1e-20
+    assert np.abs(x.cpu().numpy() - xs).max() < 1e-8
+    # L = f - lambda.c: stationarity d x - b - lambda_j = 0 on S_j  ->  lambda_j = nu_j
+    assert np.abs(out["lambda"].cpu().numpy() - nu).max() < 1e-7

@@ -46,3 +46,14 @@ def test_compiled_code_objects_are_cached_on_disk(tmp_path, monkeypatch):
     assert files[0].stat().st_mtime_ns == stamp and len(list(tmp_path.glob("fl_user_*"))) == 1
     assert NLO.compile_check(US.DIAGQUAD + "\n// changed\n", "MyQuadratic", 512, 2, 2)[0] == 0
     assert len(list(tmp_path.glob("fl_user_*.co"))) == 2
+
+
+def test_constraints_functor_sources_compile_too():
+    """(through the Python wrapper's GPU-less path there is only the plain kernel: compile the constrained program by hand)"""
+    import ctypes as C
+    NLO = _nlo()
+    NLO.FL.fl_user_compile_check_auglag.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_size_t]
+    log = C.create_string_buffer(1 << 16)
+    for cons in (b"MySpheres", b""):
+        rc = NLO.FL.fl_user_compile_check_auglag((US.DIAGQUAD + US.BLOCK_SPHERES).encode(), b"MyQuadratic", cons, 2, 512, 2, b"gfx950", log, len(log))
+        assert rc == 0, log.value.decode()[:2000]

@@ -94,3 +94,70 @@ template <int NW, int EPT> struct Oops {
     __device__ static double combine(double s0, double) { return s0; }
 };
 """
+
+# ---- constraints of the caller's own (fl_user_compile_auglag with a constraints class; NO.f90:1928-1934: c, cd)
+# M block spheres c_j = sum_{i in block j} x_i^2 - 1 over M consecutive blocks of n / M elements: the library's own family
+# restated as a USER functor (held to the built-in kernel and to the oracle bit for bit)
+BLOCK_SPHERES = r"""
+template <int NW, int EPT> struct MySpheres {
+    using G = fl::Geo<NW, EPT>;
+    int w, m;
+    __device__ void init(const fl::SolveArgs &A, int) { m = A.aug_m; w = A.n / A.aug_m; }
+    __device__ void partial(const double (&x)[EPT], double (&cp)[8], int n)
+    {
+        for (int j = 0; j < 8; ++j) {
+            double acc = 0.0;
+            for (int k = 0; k < EPT; ++k) {
+                const int e = G::e0(k >> 1) + (k & 1);
+                const double t = (e < n && e / w == j) ? x[k] * x[k] : 0.0;
+                acc = (k == 0) ? t : acc + t;
+            }
+            cp[j] = acc;
+        }
+    }
+    __device__ double offset(int) const { return -1.0; }
+    __device__ void add_gradient(const double (&x)[EPT], const double (&v)[8], double (&g)[EPT], int n)
+    {
+        for (int k = 0; k < EPT; ++k) {
+            const int e = G::e0(k >> 1) + (k & 1);
+            if (e < n) {
+                double vv = 0.0;
+                for (int j = 0; j < 8; ++j) vv = (e / w == j) ? v[j] : vv;
+                g[k] = g[k] + (2.0 * x[k]) * vv;
+            }
+        }
+    }
+};
+"""
+
+# M LINEAR constraints over interleaved index sets: c_j = sum_{i = j mod M} x_i - 1 (any n; nothing like the built-in family)
+STRIDE_SUMS = r"""
+template <int NW, int EPT> struct MyStrideSums {
+    using G = fl::Geo<NW, EPT>;
+    int m;
+    __device__ void init(const fl::SolveArgs &A, int) { m = A.aug_m; }
+    __device__ void partial(const double (&x)[EPT], double (&cp)[8], int n)
+    {
+        for (int j = 0; j < 8; ++j) {
+            double acc = 0.0;
+            for (int k = 0; k < EPT; ++k) {
+                const int e = G::e0(k >> 1) + (k & 1);
+                acc = acc + ((e < n && e % m == j) ? x[k] : 0.0);
+            }
+            cp[j] = acc;
+        }
+    }
+    __device__ double offset(int) const { return -1.0; }
+    __device__ void add_gradient(const double (&x)[EPT], const double (&v)[8], double (&g)[EPT], int n)
+    {
+        for (int k = 0; k < EPT; ++k) {
+            const int e = G::e0(k >> 1) + (k & 1);
+            if (e < n) {
+                double vv = 0.0;
+                for (int j = 0; j < 8; ++j) vv = (e % m == j) ? v[j] : vv;
+                g[k] = g[k] + vv;
+            }
+        }
+    }
+};
+"""
