@@ -335,6 +335,10 @@ def minimize_rci(solver, x, fun, options=None, max_steps=10000000, check_every=8
     mode="full":   `fun(x, request)` as above, but f AND g are taken at every point (FL_RCI_BOTH): one step per distinct
         trial point, like the fused kernels.  Finished problems cost one word per step on the device; the objective still
         sees the whole batch (request[k] == 0 marks the rows it may skip).
+    mode="graph":  as "full", with one round -- the objective and the step kernel -- captured ONCE in a HIP graph and replayed: the
+        ~10 launches of a round cost one graph launch (small and medium batches are launch-bound: tools/bench_configs.py rcigraph).
+        `fun(x, request)` must be stream-capturable torch code (no host synchronisation, fixed shapes); `check_every` rounds
+        run between two looks at the requests.  n <= 4096, no Hessians.
     mode="compact" (SD | CG | LBFGS_): `fun(xc, request, ids, epoch)` gets only the ACTIVE problems: xc [n_active, n], their
         problem ids [n_active] and a counter that changes whenever the list does (so that per-problem data can be
         gathered once per change, not per call); returns (f[n_active], g[n_active, n]).  The list is re-compacted when
@@ -353,11 +357,49 @@ def minimize_rci(solver, x, fun, options=None, max_steps=10000000, check_every=8
     if wants_h and (hess is None or mode != "legacy"):
         raise ValueError("NewtonRaphson / BFGS with ExactStep > 0 by reverse communication: pass hess=callable | 'numerical' (mode 'legacy')")
     h = C.c_void_p()
-    _check(FL.fl_rci_create(C.byref(h), solver, B, n, C.byref(o), _stream()), "fl_rci_create")
+    side = None
+    if mode == "graph":  # the handle lives on a stream of its own: the one the step + objective sequence is captured on
+        if wants_h or n > 4096:
+            raise ValueError("mode 'graph': SD / CG / L-BFGS / quasi-Newton BFGS, n <= 4096")
+        side = torch.cuda.Stream(device=x.device)
+        side.wait_stream(torch.cuda.current_stream())
+        _check(FL.fl_rci_create(C.byref(h), solver, B, n, C.byref(o), C.c_void_p(side.cuda_stream)), "fl_rci_create")
+    else:
+        _check(FL.fl_rci_create(C.byref(h), solver, B, n, C.byref(o), _stream()), "fl_rci_create")
     try:
         req = torch.empty(B, dtype=torch.int32, device=x.device)
         steps = 0
-        if mode == "compact":
+        if mode == "graph":
+            # One evaluation round -- the caller's objective (torch operations on fixed tensors) and the step kernel -- captured
+            # ONCE in a HIP graph and replayed: the ~10 launches of a round cost one graph launch.  `fun` must be capturable
+            # (no host synchronisation, no data-dependent shapes); every point asked for is evaluated for f AND f' (FL_RCI_BOTH).
+            fbuf = torch.empty(B, dtype=torch.float64, device=x.device)
+            gbuf = torch.empty(B, n, dtype=torch.float64, device=x.device)
+            with torch.cuda.stream(side):
+                _check(FL.fl_rci_step_flags(h, _ptr(x), None, None, _ptr(req), RCI_BOTH), "fl_rci_step_flags")
+                for _ in range(2):  # warm-up rounds outside the capture (allocator, lazy initialisation), real steps of the solve
+                    fn, gn = fun(x, req)
+                    fbuf.copy_(fn)
+                    gbuf.copy_(gn)
+                    _check(FL.fl_rci_step_flags(h, _ptr(x), _ptr(fbuf), _ptr(gbuf), _ptr(req), RCI_BOTH), "fl_rci_step_flags")
+                    steps += 1
+            side.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            rcs = []
+            with torch.cuda.graph(graph, stream=side):
+                fn, gn = fun(x, req)
+                fbuf.copy_(fn)
+                gbuf.copy_(gn)
+                rcs.append(FL.fl_rci_step_flags(h, _ptr(x), _ptr(fbuf), _ptr(gbuf), _ptr(req), RCI_BOTH))
+            _check(rcs[0], "fl_rci_step_flags (captured)")
+            while steps < max_steps:
+                if not bool((req != 0).any()):
+                    break
+                for _ in range(check_every):
+                    graph.replay()
+                steps += check_every
+            torch.cuda.current_stream().wait_stream(side)
+        elif mode == "compact":
             ids = torch.arange(B, dtype=torch.int32, device=x.device)
             xc = x.clone()
             na, epoch = B, 0

@@ -805,3 +805,28 @@ def test_augmented_lagrangian_exact_inner_solvers_refuse_n_beyond_2048():
     x = torch.zeros(1, 2560, dtype=torch.float64, device=dev)
     with pytest.raises(Exception):
         NLO.AugmentedLagrangian(O.QUARTIC, x, 4, UnconstrainedSolver="NewtonRaphson")
+
+
+def test_rci_round_captured_in_a_hip_graph_walks_the_same_path():
+    """minimize_rci(mode="graph"): the objective (torch) + fl_rci_step_flags captured once and replayed -- same bits as the
+    eager "full" mode (and the oracle), L-BFGS and CG, finished problems riding along for the extra rounds of a replay batch"""
+    NLO = _nlo()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    B, n = 40, 256
+    d, b = _quads(B, n, 10.0, 300.0, 3)
+    dd, bb = torch.tensor(d, device=dev), torch.tensor(b, device=dev)
+
+    def fun(xx, req=None):
+        dx = dd * xx
+        return 0.5 * (dx * xx).sum(1) - (bb * xx).sum(1), dx - bb
+    for solver in (NLO.LBFGS_, NLO.CG):
+        res = {}
+        for mode in ("full", "graph"):
+            x = torch.zeros(B, n, dtype=torch.float64, device=dev)
+            out = NLO.minimize_rci(solver, x, fun, mode=mode, Precision=1e-8, MaxIteration=300, check_every=16)
+            res[mode] = (x.clone(), out)
+        assert torch.equal(res["full"][0], res["graph"][0])
+        for k in ("f", "iters", "nf", "ng", "status"):
+            assert torch.equal(res["full"][1][k], res["graph"][1][k]), k
+        assert int(res["graph"][1]["iters"].min()) > 5

@@ -443,6 +443,31 @@ def main():
                               "max_rel_x_diff_vs_fused": float(((x - xf).norm(dim=1) / xf.norm(dim=1)).max()),
                               "slowdown_vs_fused": dt * 1e3 / msf}))
 
+    if "rcigraph" in args.configs:  # the round-trip budget of reverse communication per step: eager launches vs one HIP graph per round
+        n, m = 1024, 10
+        for B in (256, 2048, 16384):
+            d, b = quad(B, n, 10.0, 1000.0)
+            x = torch.zeros(B, n, dtype=torch.float64, device=dev)
+
+            def fun(xx, req=None):
+                dx = d * xx
+                return 0.5 * (dx * xx).sum(1) - (b * xx).sum(1), dx - b
+            first = None
+            for mode in ("full", "graph"):
+                NLO.minimize_rci(NLO.LBFGS_, x.zero_(), fun, mode=mode, Precision=1e-6, MaxIteration=20, Memory=m, check_every=32)  # warm-up
+                x.zero_()
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                out = NLO.minimize_rci(NLO.LBFGS_, x, fun, mode=mode, Precision=1e-6, MaxIteration=3000, Memory=m, check_every=32)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t
+                it = int(out["iters"].to(torch.int64).sum())
+                if first is None:
+                    first = x.clone()
+                print(json.dumps({"config": f"RCI round trip ({mode}) L-BFGS m=10, diagonal quadratics n=1024, batch {B}, torch objective",
+                                  "ms": dt * 1e3, "steps": out["steps"], "us_per_step": dt * 1e6 / max(1, out["steps"]),
+                                  "iterations_per_s": it / dt, "same_bits_as_full": bool(torch.equal(x, first))}), flush=True)
+
     if "coop" in args.configs:  # ONE problem of n = 2^20 (the reference's callers: one problem of any dim) by reverse communication
         n, m = 1 << 20, 10
         i = torch.arange(n, dtype=torch.float64, device=dev)
