@@ -184,3 +184,25 @@ def test_reference_python_package_imports_against_this_library():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env, cwd="/tmp")
     assert out.returncode == 0, out.stderr
     assert " year " in out.stdout and "SN 1.2345" in out.stdout and out.stdout.strip().endswith(" 3")
+
+
+def test_augmented_lagrangian_launch_plan_by_batch():
+    """include/fl_nlopt.h fl_augmented_lagrangian_launch_plan: helper waves by batch for the start of the launch, unfinished
+    problems handed to stages with more waves; only where the kernel has helper-wave forms; independent of a GPU being present
+    (256 CUs assumed without one)."""
+    import FortranLibrary.NonlinearOptimization as NLO
+    P = NLO.augmented_lagrangian_launch_plan
+    assert P(NLO.LBFGS_, NLO.DIAGQUAD, 256, 512, 8) == [(4, 0)]
+    assert P(NLO.LBFGS_, NLO.DIAGQUAD, 1024, 512, 8) == [(2, 512), (4, 0)]
+    assert P(NLO.LBFGS_, NLO.DIAGQUAD, 8192, 512, 8) == [(1, 1536), (2, 512), (4, 0)]
+    assert P(NLO.CG, NLO.QUARTIC, 8192, 256, 8) == [(1, 1536), (2, 512), (4, 0)]
+    # no helper-wave form: another objective, a dense inner solver, two waves per problem, blocks that are not lane groups
+    assert P(NLO.LBFGS_, NLO.ROSENBROCK, 8192, 512, 8) == [(1, 0)]
+    assert P(NLO.BFGS_, NLO.DIAGQUAD, 8192, 512, 8) == [(1, 0)]
+    assert P(NLO.LBFGS_, NLO.DIAGQUAD, 8192, 1024, 8) == [(2, 0)]
+    assert P(NLO.LBFGS_, NLO.DIAGQUAD, 8192, 200, 5) == [(1, 0)]
+    os.environ["FL_AUG_STAGED"] = "0"
+    try:
+        assert P(NLO.LBFGS_, NLO.DIAGQUAD, 8192, 512, 8) == [(1, 0)] and P(NLO.LBFGS_, NLO.DIAGQUAD, 1024, 512, 8) == [(2, 0)]
+    finally:
+        del os.environ["FL_AUG_STAGED"]
