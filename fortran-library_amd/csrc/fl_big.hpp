@@ -419,6 +419,13 @@ template <int OBJ, int METHOD> struct BigSolver {
     // ---------------------------------------------------------------- machine (Solver::advance and friends)
     // (an objective that is not a number ends the problem: see Solver::not_finite)
     __device__ __forceinline__ bool not_finite(double fv) const { return (pending & FL_REQ_F) && fv != fv; }
+    __device__ __forceinline__ bool in_zoom() const { return ls.st == LineSearch::SW_ZOOM || ls.st == LineSearch::WZ_F || ls.st == LineSearch::WZ_G; }
+    __device__ __forceinline__ void stop_stalled()
+    {
+        status = FL_STATUS_STALLED;
+        phase = PH_DONE;
+        pending = 0;
+    }
     __device__ __forceinline__ void stop_not_finite()
     {
         status = FL_STATUS_NOT_FINITE;

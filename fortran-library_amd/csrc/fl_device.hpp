@@ -1433,6 +1433,21 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
     // takes the device with it.  No effect on any finite run.  (In the loop, not inside advance(): an early return there cost
     // the dense augmented-Lagrangian kernels 10-70 spilled VGPRs.)
     __device__ __forceinline__ bool not_finite(double fv) const { return (pending & FL_REQ_F) && fv != fv; }
+    // ... and so does a zoom that never narrows (FL_STATUS_STALLED).  The reference's zoom has no iteration limit (NO.f90:1557-1579,
+    // Wolfe's: 1347-1370): found on the quartic + block spheres at x -> 1/8 with both end slopes positive at the rounding level, where
+    // the interpolation returns to the same two points for ever -- the oracle, restating the reference, never returns there either
+    // (tests/test_gpu_helpers.py: problem 1724 of that family).  FL_ZOOM_CAP consecutive zoom trials -- a zoom that works needs
+    // ~60 to halve an interval down to 1e-15 -- end the problem where it is.
+#ifndef FL_ZOOM_CAP
+#define FL_ZOOM_CAP 65536
+#endif
+    __device__ __forceinline__ bool in_zoom() const { return ls.st == LineSearch::SW_ZOOM || ls.st == LineSearch::WZ_F || ls.st == LineSearch::WZ_G; }
+    __device__ __forceinline__ void stop_stalled()
+    {
+        status = FL_STATUS_STALLED;
+        phase = PH_DONE;
+        pending = 0;
+    }
     __device__ __forceinline__ void stop_not_finite()
     {
         status = FL_STATUS_NOT_FINITE;

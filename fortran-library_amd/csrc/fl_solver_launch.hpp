@@ -49,6 +49,7 @@ void fl_solve_kernel(SolveArgs A)
     s.init();
     int rq = s.start();
     double fv = 0.0, pv = 0.0, gg = 0.0;
+    int zoom_run = 0;    // consecutive trials of the line search's zoom
     bool have_g = false; // augmented Lagrangian: objective-only trials skip the gradient until it is asked for
     constexpr int SK = S::SPEC_K;
 #ifdef FL_PHASE_TIMERS // tuning builds only (tools/phase_timers.py): where a problem's wall time goes, in 10 ns ticks, to A.user
@@ -119,6 +120,12 @@ void fl_solve_kernel(SolveArgs A)
                 s.stop_not_finite();
                 rq = 0;
             }
+            // ... and a zoom that never narrows (Solver::in_zoom: the reference's has no iteration limit)
+            zoom_run = s.in_zoom() ? zoom_run + 1 : 0;
+            if (zoom_run > FL_ZOOM_CAP) {
+                s.stop_stalled();
+                rq = 0;
+            }
 #ifdef FL_PHASE_TIMERS
             if (s.iters + s.inner_iters_total != it0) FL_T1(5); // a line search ended: convergence tests + the new direction
             else FL_T1(4);
@@ -167,6 +174,7 @@ __global__ __launch_bounds__(REP * NW * 64) void fl_solve_rep_kernel(SolveArgs A
     s.init();
     int rq = master ? s.start() : 0;
     double fv = 0.0, pv = 0.0, gg = 0.0;
+    int zoom_run = 0;
     bool have_g = false;
     for (;;) { // one turn = one request of the master's machine (one call site of advance(): it is inlined once)
         int c = 0; // 1: a shrink loop is shared out behind the next barrier, 2: the problem is finished
@@ -218,6 +226,11 @@ __global__ __launch_bounds__(REP * NW * 64) void fl_solve_rep_kernel(SolveArgs A
                 rq = 0;
             } else {
                 rq = s.advance(fv, pv, gg);
+                zoom_run = s.in_zoom() ? zoom_run + 1 : 0;
+                if (zoom_run > FL_ZOOM_CAP) { // (a zoom that never narrows: Solver::in_zoom)
+                    s.stop_stalled();
+                    rq = 0;
+                }
             }
         }
     }

@@ -59,6 +59,9 @@ extern "C" {
 #define FL_STATUS_NOT_FINITE 4     /* fused kernels: the objective returned NaN -- the problem stops where it is (the       */
                                    /* reference's line searchers would never return: their loops end on comparisons,       */
                                    /* NO.f90:1557-1579; by reverse communication the loop is the caller's)                 */
+#define FL_STATUS_STALLED 5        /* fused kernels: the line search's zoom did not narrow its bracket in 65 536 consecutive  */
+                                   /* trials -- the reference's zoom has no iteration limit and never returns on such a      */
+                                   /* problem (NO.f90:1557-1579); the problem stops at the last trial point                  */
 #define FL_STATUS_NOT_SOLVED (-1)  /* fl_multi_solve only: the shard holding this problem failed (allocation, launch); */
                                    /* its rows of x and of the outputs are untouched                                  */
 

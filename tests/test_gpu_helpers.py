@@ -164,3 +164,67 @@ def test_staged_launches_equal_the_single_launch(monkeypatch):
             assert torch.equal(res["1"][1][k], res["0"][1][k]), (kw, k)
         assert int((res["1"][1]["status"] == 3).sum()) == 0
     monkeypatch.delenv("FL_AUG_STAGED", raising=False)
+
+
+@pytest.mark.parametrize("n,M,inner,kind,B", [(256, 8, "ConjugateGradient", "DIAGQUAD", 6000), (256, 4, "LBFGS", "QUARTIC", 3000), (384, 3, "LBFGS", "DIAGQUAD", 2000)])
+def test_staged_launches_on_the_other_helper_kernels(monkeypatch, n, M, inner, kind, B):
+    """the one-wave x 4 geometry (n <= 256), ConjugateGradient inside, the quartic objective (x0 in registers: published to the
+    helpers per loop), block width 128: staged = single launch, bit for bit, at batches that take two and three stages"""
+    NLO = _nlo()
+    monkeypatch.delenv("FL_FORCE_REPLICAS", raising=False)
+    dev = torch.device("cuda:0")
+    kobj = getattr(NLO, kind)
+    x0 = torch.empty(B, n, dtype=torch.float64, device=dev)
+    d = b = None
+    if kind == "DIAGQUAD":
+        d = torch.empty_like(x0)
+        b = torch.empty_like(x0)
+        NLO.synth_diag_spectrum(7, d, 2.0, 10.0)
+        NLO.synth_uniform(7, b, -1.0, 1.0)
+        NLO.synth_uniform(8, x0, 0.05, 0.15)
+    else:
+        NLO.synth_uniform(8, x0, 0.0, 1.0)
+    solver = NLO.LBFGS_ if inner == "LBFGS" else NLO.CG
+    assert len(NLO.augmented_lagrangian_launch_plan(solver, kobj, B, n, M)) >= 2
+    res = {}
+    for staged in ("1", "0"):
+        monkeypatch.setenv("FL_AUG_STAGED", staged)
+        x = x0.clone()
+        out = NLO.AugmentedLagrangian(kobj, x, M, d, b, UnconstrainedSolver=inner, Precision=1e-9, MaxIteration=40)
+        torch.cuda.synchronize()
+        res[staged] = (x, out)
+    assert torch.equal(res["1"][0], res["0"][0])
+    for k in ("f", "nf", "ng", "iters", "outer", "lambda", "cnorm2", "status"):
+        assert torch.equal(res["1"][1][k], res["0"][1][k]), k
+    assert int((res["1"][1]["status"] == 3).sum()) == 0
+
+
+def test_a_zoom_that_never_narrows_ends_the_problem_instead_of_the_kernel_running_for_ever(monkeypatch):
+    """FL_STATUS_STALLED (include/fl_nlopt.h).  Found in round 4: problem 1724 of the quartic + 4 block spheres family (n = 256,
+    x0 uniform in (0, 1), Philox seed 8) converges to x = 1/8, and in its tenth outer round the reference's zoom
+    (NO.f90:1557-1579, no iteration limit) returns to the same two points for ever, both end slopes positive at the rounding
+    level -- the oracle, restating the reference, never returns on it either (which is why it is skipped below), and the
+    round-3 kernel ran until it was killed.  Now 65 536 consecutive zoom trials end the problem; its neighbours are solved as
+    ever (bit for bit the oracle), with and without helper waves."""
+    import philox_ref as P
+    NLO = _nlo()
+    dev = torch.device("cuda:0")
+    n, M, lo, hi, bad = 256, 4, 1700, 1764, 1724
+    x0 = P.philox_uniform(8, 3000, n, 0.0, 1.0)[lo:hi]
+    res = {}
+    for rep in ("1", "4"):
+        monkeypatch.setenv("FL_FORCE_REPLICAS", rep)
+        x = torch.tensor(x0, device=dev)
+        out = NLO.AugmentedLagrangian(NLO.QUARTIC, x, M, UnconstrainedSolver="LBFGS", Precision=1e-9, MaxIteration=40)
+        torch.cuda.synchronize()
+        res[rep] = dict({k: v.cpu().numpy() for k, v in out.items() if k != "workspace"}, x=x.cpu().numpy())
+    for k, v in res["1"].items():
+        assert np.array_equal(v, res["4"][k]), k
+    st = res["1"]["status"]
+    assert st[bad - lo] == 5 and np.all(np.delete(st, bad - lo) != 5), st
+    assert np.all(np.isfinite(res["1"]["x"])) and abs(np.abs(res["1"]["x"][bad - lo]).mean() - 0.125) < 1e-3  # (x -> +-1/8, it stopped next to it)
+    keep = np.array([k for k in range(hi - lo) if k != bad - lo])
+    T, E = NLO.reduction_geometry(n)
+    o = O.auglag_batch(O.LBFGS, O.QUARTIC, x0[keep], M, opts=O.defaults(precision=1e-9, maxit=40), sum_mode=O.TREE, threads=T, ept=E)
+    assert np.array_equal(res["1"]["x"][keep].view(np.uint64), o["x"].view(np.uint64))
+    assert np.array_equal(res["1"]["nf"][keep], o["nf"]) and np.array_equal(res["1"]["outer"][keep], o["outer"])
