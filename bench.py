@@ -918,6 +918,40 @@ def config_c5(ctx, NLO, prof, cpu_seconds):
     return res
 
 
+def rtc_leg(ctx, NLO):
+    """The caller's objective handed over as SOURCE TEXT (fl_user_compile: hiprtc at run time, csrc/fl_user_rtc.hip) against the
+    built-in objective on the headline family -- 16 384 problems, L-BFGS m = 10, n = 1024: compile time, solve time, bits.  The
+    reference takes the objective as callbacks (NO.f90:33-38); reverse communication (fl_rci_*) is the other way to pass one."""
+    torch = ctx.torch
+    try:
+        import user_sources as US
+    except ImportError:
+        return {"skipped": "tests/user_sources.py not found"}
+    B, n, m = 16384, 1024, 10
+    d, b = _quad(ctx, NLO, B, n, 10.0, 1000.0)
+    x = torch.zeros(B, n, dtype=torch.float64, device=ctx.dev)
+    ws = NLO.workspace(B, n, m, ctx.dev)
+    t = time.perf_counter()
+    obj = NLO.compile_objective(US.DIAGQUAD, "MyQuadratic", n, solver=NLO.LBFGS_, tune_like=NLO.DIAGQUAD)
+    compile_s = time.perf_counter() - t
+
+    def builtin():
+        x.zero_()
+        return NLO.LBFGS(NLO.DIAGQUAD, x, d, b, workspace_=ws, Precision=1e-6, MaxIteration=3000, Memory=m)
+
+    def compiled():
+        x.zero_()
+        return obj.solve(x, d, b, None, workspace_=ws, Precision=1e-6, MaxIteration=3000, Memory=m)
+    ob, mb = timed_launches(ctx, builtin, 3)
+    xb = x.clone()
+    ou, mu = timed_launches(ctx, compiled, 3)
+    same = bool(torch.equal(x, xb) and all(torch.equal(ou[k], ob[k]) for k in ("f", "iters", "nf", "ng", "status")))
+    it = float(ou["iters"].to(torch.int64).sum())
+    return {"workload": f"L-BFGS m={m}, diagonal quadratics n={n}, {B} problems; the objective given as HIP source text", "compile_seconds": compile_s,
+            "ms_compiled": mu, "ms_builtin": mb, "iterations_per_s_compiled": it / mu * 1e3, "speed_vs_builtin": mb / mu,
+            "same_bits_as_builtin": same, "note": "timed with the memset of x inside (both legs alike)"}
+
+
 CONFIGS = {"c2": config_c2, "c3": config_c3, "c4": config_c4, "c4gemm": config_c4gemm, "c5": config_c5}
 MULTI_GPU_CONFIGS = ("c3", "c5")  # BASELINE.json: "sharded 1/2/4/8 GPUs", "8xMI355X"
 
@@ -1021,6 +1055,9 @@ def main():
         cfgs = run_configs(ctx, NLO, names, False, args.config_cpu_seconds)
         if ctx.rank == 0:
             res["configs"] = cfgs
+
+    if names and ctx.world == 1 and ctx.rank == 0:
+        res["user_objective_compiled_at_run_time"] = rtc_leg(ctx, NLO)
 
     bad = False
     if ctx.rank == 0:
