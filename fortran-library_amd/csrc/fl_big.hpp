@@ -255,6 +255,7 @@ template <int OBJ, int METHOD> struct BigSolver {
     }
     __device__ __forceinline__ int start()
     {
+        ls.zn = 0; // (must_stop() reads it before the first search begins)
         phase = PH_INIT;
         pending = FL_REQ_F | FL_REQ_G | FL_REQ_NOMOVE;
         return pending;
@@ -419,17 +420,15 @@ template <int OBJ, int METHOD> struct BigSolver {
     // ---------------------------------------------------------------- machine (Solver::advance and friends)
     // (an objective that is not a number ends the problem: see Solver::not_finite)
     __device__ __forceinline__ bool not_finite(double fv) const { return (pending & FL_REQ_F) && fv != fv; }
-    __device__ __forceinline__ bool in_zoom() const { return ls.st == LineSearch::SW_ZOOM || ls.st == LineSearch::WZ_F || ls.st == LineSearch::WZ_G; }
-    __device__ __forceinline__ void stop_stalled()
-    {
-        status = FL_STATUS_STALLED;
-        phase = PH_DONE;
-        pending = 0;
-    }
+    __device__ __forceinline__ bool must_stop(double fv) const { return not_finite(fv) || ls.stalled(); } // (Solver::must_stop)
     __device__ __forceinline__ void stop_not_finite()
     {
-        status = FL_STATUS_NOT_FINITE;
-        fnew = __builtin_nan(""); // (not the value itself: it would have to stay in registers across advance())
+        if (ls.stalled()) {
+            status = FL_STATUS_STALLED;
+        } else {
+            status = FL_STATUS_NOT_FINITE;
+            fnew = __builtin_nan("");
+        }
         phase = PH_DONE;
         pending = 0;
     }

@@ -747,6 +747,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
     }
     __device__ __forceinline__ int start()
     {
+        ls.zn = 0; // (must_stop() reads it before the first search begins)
         phase = PH_INIT;
         pending = FL_REQ_F | FL_REQ_G | FL_REQ_NOMOVE;
         return pending;
@@ -1436,22 +1437,18 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
     // ... and so does a zoom that never narrows (FL_STATUS_STALLED).  The reference's zoom has no iteration limit (NO.f90:1557-1579,
     // Wolfe's: 1347-1370): found on the quartic + block spheres at x -> 1/8 with both end slopes positive at the rounding level, where
     // the interpolation returns to the same two points for ever -- the oracle, restating the reference, never returns there either
-    // (tests/test_gpu_helpers.py: problem 1724 of that family).  FL_ZOOM_CAP consecutive zoom trials -- a zoom that works needs
-    // ~60 to halve an interval down to 1e-15 -- end the problem where it is.
-#ifndef FL_ZOOM_CAP
-#define FL_ZOOM_CAP 65536
-#endif
-    __device__ __forceinline__ bool in_zoom() const { return ls.st == LineSearch::SW_ZOOM || ls.st == LineSearch::WZ_F || ls.st == LineSearch::WZ_G; }
-    __device__ __forceinline__ void stop_stalled()
+    // (tests/test_gpu_helpers.py: problem 1724 of that family).  The machine counts its zoom trials (LineSearch::zn); beyond
+    // FL_ZOOM_CAP the problem ends where it is.  ONE flag for both conditions, so that the kernels' loops carry one test: a
+    // second test of their own cost C3 2-5 %.
+    __device__ __forceinline__ bool must_stop(double fv) const { return not_finite(fv) || ls.stalled(); }
+    __device__ __forceinline__ void stop_not_finite() // (behind must_stop(): which of the two it was is still in ls.zn)
     {
-        status = FL_STATUS_STALLED;
-        phase = PH_DONE;
-        pending = 0;
-    }
-    __device__ __forceinline__ void stop_not_finite()
-    {
-        status = FL_STATUS_NOT_FINITE;
-        fnew = __builtin_nan(""); // (not the value itself: it would have to stay in registers across advance())
+        if (ls.stalled()) {
+            status = FL_STATUS_STALLED;
+        } else {
+            status = FL_STATUS_NOT_FINITE;
+            fnew = __builtin_nan(""); // (not the value itself: it would have to stay in registers across advance())
+        }
         phase = PH_DONE;
         pending = 0;
     }

@@ -37,6 +37,13 @@
 #define FL_REQ_G 2
 #define FL_REQ_SAME 4
 
+// A zoom that works needs ~60 trials to halve an interval down to 1e-15; the reference's has no iteration limit at all
+// (NO.f90:1557-1579, Wolfe's: 1347-1370) and can cycle between two points for ever: the machine ends the
+// machine counts its zoom trials and the fused kernels end a problem beyond this many (Solver::must_stop: FL_STATUS_STALLED).
+#ifndef FL_ZOOM_CAP
+#define FL_ZOOM_CAP 65536
+#endif
+
 namespace fl {
 
 struct LineSearch {
@@ -52,6 +59,7 @@ struct LineSearch {
     double a, aold, fx, fold, phidnew, phidold;
     double low, up, flow, fup, phidlow, phidup, plma; // zoom's arguments; plma = phidlow_m_a
     int st, zret;
+    int zn; // trials of the zoom in this search (more than FL_ZOOM_CAP: stalled() -- the reference's zoom has no limit)
     double a_eval; // where the pending request is to be evaluated
 
     // Every value of the machine is uniform across the workgroup.  On the GPU, pin the state to
@@ -106,12 +114,14 @@ struct LineSearch {
         st = DONE;
         return 0;
     }
+    FL_HD bool stalled() const { return zn > FL_ZOOM_CAP; } // (until the next begin())
     FL_HD bool armijo() const { return fx <= fx0 + c1 * a * phid0; }
 
     // c1, c2 as clamped by the solver; increment as passed (fail-safe NO.f90:1478)
     FL_HD int begin(int strong, int fused_, double c1_, double c2_, double increment, double a0, double fx_in,
                     double phid0_in)
     {
+        zn = 0;
         c1 = c1_;
         incr = dmax(1.0 + 1e-15, increment);
         fused = fused_;
@@ -296,6 +306,7 @@ struct LineSearch {
         case SW_LAST_G:
             return done();
         case SW_ZOOM: { // NO.f90:1567-1577
+            ++zn;
             fx = fv;
             const double pn = pv;
             if (fx > fx0 + c1 * a * phid0 || fx >= flow) {
@@ -358,6 +369,7 @@ struct LineSearch {
         case W_LAST_G:
             return done();
         case WZ_F: // NO.f90:1355-1362
+            ++zn;
             fx = fv;
             if (fx > fx0 + c1 * a * phid0) {
                 up = a;

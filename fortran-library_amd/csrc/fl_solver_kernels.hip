@@ -30,22 +30,16 @@ template <int OBJ, int METHOD> __global__ __launch_bounds__(1024) void fl_big_so
     s.clear_rows();
     int rq = s.start();
     double fv = 0.0, pv = 0.0, gg = 0.0;
-    int zoom_run = 0;
     while (rq) {
         if (!(rq & FL_REQ_SAME)) {
             if (rq & FL_REQ_NOMOVE) s.evaluate(fv, pv, gg);
             else s.move_evaluate(s.request_point(), fv, pv, gg); // the trial point is formed and evaluated in one pass
         }
-        if (s.not_finite(fv)) { // (see Solver::not_finite)
+        if (s.must_stop(fv)) { // (see Solver::must_stop)
             s.stop_not_finite();
             break;
         }
         rq = s.advance(fv, pv, gg);
-        zoom_run = s.in_zoom() ? zoom_run + 1 : 0;
-        if (zoom_run > FL_ZOOM_CAP) { // (see Solver::in_zoom)
-            s.stop_stalled();
-            break;
-        }
     }
     s.finish();
 }

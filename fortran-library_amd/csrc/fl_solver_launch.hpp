@@ -49,7 +49,6 @@ void fl_solve_kernel(SolveArgs A)
     s.init();
     int rq = s.start();
     double fv = 0.0, pv = 0.0, gg = 0.0;
-    int zoom_run = 0;    // consecutive trials of the line search's zoom
     bool have_g = false; // augmented Lagrangian: objective-only trials skip the gradient until it is asked for
     constexpr int SK = S::SPEC_K;
 #ifdef FL_PHASE_TIMERS // tuning builds only (tools/phase_timers.py): where a problem's wall time goes, in 10 ns ticks, to A.user
@@ -114,16 +113,10 @@ void fl_solve_kernel(SolveArgs A)
             // takes one step of the machine with the NaN: a step has no loops -- and acted upon behind it, so that the loop keeps
             // its one way out and no value stays live across advance() for it (a `break` before advance() cost the dense BFGS
             // kernel 130 more spilled SGPRs, handing advance() a clean value the n <= 256 L-BFGS kernel 2 spilled VGPRs)
-            const bool nanv = s.not_finite(fv);
+            const bool nanv = s.must_stop(fv); // (... or a zoom that never narrows: Solver::must_stop)
             rq = s.advance(fv, pv, gg);
             if (nanv) {
                 s.stop_not_finite();
-                rq = 0;
-            }
-            // ... and a zoom that never narrows (Solver::in_zoom: the reference's has no iteration limit)
-            zoom_run = s.in_zoom() ? zoom_run + 1 : 0;
-            if (zoom_run > FL_ZOOM_CAP) {
-                s.stop_stalled();
                 rq = 0;
             }
 #ifdef FL_PHASE_TIMERS
@@ -174,7 +167,6 @@ __global__ __launch_bounds__(REP * NW * 64) void fl_solve_rep_kernel(SolveArgs A
     s.init();
     int rq = master ? s.start() : 0;
     double fv = 0.0, pv = 0.0, gg = 0.0;
-    int zoom_run = 0;
     bool have_g = false;
     for (;;) { // one turn = one request of the master's machine (one call site of advance(): it is inlined once)
         int c = 0; // 1: a shrink loop is shared out behind the next barrier, 2: the problem is finished
@@ -221,16 +213,13 @@ __global__ __launch_bounds__(REP * NW * 64) void fl_solve_rep_kernel(SolveArgs A
                 s.template evaluate<true>(fv, pv, gg);
                 have_g = true;
             }
-            if (s.not_finite(fv)) { // (the objective is not a number: the problem ends here; the helpers are released below)
+            // (the objective is not a number, or the zoom never narrows: the problem ends here, in the form -- and so with the
+            // counters -- of fl_solve_kernel's loop; the helpers are released at the top of the next turn)
+            const bool stop = s.must_stop(fv);
+            rq = s.advance(fv, pv, gg);
+            if (stop) {
                 s.stop_not_finite();
                 rq = 0;
-            } else {
-                rq = s.advance(fv, pv, gg);
-                zoom_run = s.in_zoom() ? zoom_run + 1 : 0;
-                if (zoom_run > FL_ZOOM_CAP) { // (a zoom that never narrows: Solver::in_zoom)
-                    s.stop_stalled();
-                    rq = 0;
-                }
             }
         }
     }
