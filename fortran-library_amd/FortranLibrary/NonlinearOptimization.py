@@ -236,7 +236,7 @@ def AugmentedLagrangian(objective, x, M, d=None, b=None, UnconstrainedSolver="LB
                         workspace_=None, options=None, **kw):
     """Batched augmented Lagrangian with M block-sphere equality constraints (reference: subroutine
     AugmentedLagrangian, NO.f90:2005-2241).  UnconstrainedSolver: 'LBFGS' | 'ConjugateGradient' | 'BFGS' | 'NewtonRaphson'
-    (the last two with the analytic Hessian of L, n <= 2048; BFGS with ExactStep=0: quasi-Newton only).  lambda0: optional [batch, M] tensor, updated in place (returned as
+    (the last two with the analytic Hessian of L, n <= 4096; BFGS with ExactStep=0: quasi-Newton only).  lambda0: optional [batch, M] tensor, updated in place (returned as
     out['lambda'])."""
     import torch
     solvers = {"LBFGS": LBFGS_, "ConjugateGradient": CG, "BFGS": BFGS_, "NewtonRaphson": 4}

@@ -308,9 +308,8 @@ static void launch_rci(Rci *h, const double *f, const double *g, const double *c
         if (h->solver == FL_SOLVER_CG) FL_RCI_AUG(FL_SOLVER_CG);
         else if (h->solver == FL_SOLVER_BFGS) FL_RCI_AUG(FL_SOLVER_BFGS);
         else if (h->solver == FL_SOLVER_NEWTON) {
-            // NewtonRaphson around the caller's Hessian of L (NO.f90:2074-2130): up to n = 2048 like the fused kernels (at
-            // 512 threads the Cholesky kernels and the constraint terms together do not fit 256 VGPRs)
-            if constexpr (NW < 8) FL_RCI_AUG(FL_SOLVER_NEWTON);
+            // NewtonRaphson around the caller's Hessian of L (NO.f90:2074-2130)
+            FL_RCI_AUG(FL_SOLVER_NEWTON);
         } else FL_RCI_AUG(FL_SOLVER_LBFGS);
         return;
     }
@@ -558,9 +557,7 @@ int fl_rci_create_auglag(fl_rci **out, int solver, int batch, int n, int m, doub
         return FL_ERR_INVALID_ARGUMENT;
     if (!opt || m < 1 || m > FL_MAX_CONSTRAINTS || !lambda_dev) return FL_ERR_INVALID_ARGUMENT;
     if (n > 4096) return FL_ERR_UNSUPPORTED_SIZE; // like fl_augmented_lagrangian_batched: the register path only
-    // NewtonRaphson, and BFGS with exact_step > 0, ask for the Hessian of L (FL_REQ_H: NO.f90:2229-2241, Ldd): up to
-    // n = 2048, like the fused kernels' own exact inner solvers
-    if ((solver == FL_SOLVER_NEWTON || (solver == FL_SOLVER_BFGS && opt->exact_step > 0)) && n > 2048) return FL_ERR_UNSUPPORTED_SIZE;
+    // NewtonRaphson, and BFGS with exact_step > 0, ask for the Hessian of L (FL_REQ_H: NO.f90:2229-2241, Ldd)
     const int rc = fl_rci_create(out, solver, batch, n, opt, stream);
     if (rc != FL_OK) return rc;
     fl::Rci &r = (*out)->r;

@@ -279,8 +279,6 @@ static int solve(int method, int objective, int batch, int n, double *x, const d
         // cdd branch, Ldd) -- the built-in objectives and constraints have one; BFGS with exact_step <= 0 never asks
         if (method != FL_SOLVER_LBFGS && method != FL_SOLVER_CG && method != FL_SOLVER_BFGS && method != FL_SOLVER_NEWTON)
             return FL_ERR_INVALID_ARGUMENT;
-        if ((method == FL_SOLVER_NEWTON || (method == FL_SOLVER_BFGS && opt->exact_step > 0)) && n > 2048)
-            return FL_ERR_UNSUPPORTED_SIZE;
         A.aug_m = aug->m;
         A.miu0 = aug->miu0;
         A.lambda = aug->lambda;

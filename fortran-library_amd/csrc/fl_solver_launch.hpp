@@ -309,12 +309,12 @@ template <int NW, int EPT, int OBJ> static hipError_t launch_m(int method, int a
 {
     if (aug) { // augmented Lagrangian around L-BFGS, CG (NO.f90:2150-2185) or quasi-Newton BFGS (2131-2148, ExactStep <= 0)
         if (method == FL_SOLVER_CG) return launch_k<NW, EPT, OBJ, FL_SOLVER_CG, 1>(A, st);
-        // NewtonRaphson / exact-Hessian BFGS around the Hessian of L (Ldd): up to n = 2048 (solve() refuses beyond: at 512
-        // threads the Cholesky kernels, the deferred updates and the constraint terms together do not fit 256 VGPRs)
-        if constexpr (NW < 8) {
-            if (method == FL_SOLVER_NEWTON) return launch_k<NW, EPT, OBJ, FL_SOLVER_NEWTON, 1>(A, st); // fdd=Ldd (2074-2130)
-            if (method == FL_SOLVER_BFGS && A.exact_step > 0) return launch_k<NW, EPT, OBJ, FL_SOLVER_BFGS, 1, 1>(A, st);
-        }
+        // NewtonRaphson / exact-Hessian BFGS around the Hessian of L (Ldd).  Every n of the register path since round 4: at
+        // 512 threads (n > 2048) the Cholesky kernels, the deferred updates and the constraint terms together fill the 256
+        // VGPRs exactly for the quadratic and Rosenbrock; the quartic's two kernels spill (22 / 130 registers, outside the
+        // streaming passes over the matrix -- tests/test_kernel_resources.py names them)
+        if (method == FL_SOLVER_NEWTON) return launch_k<NW, EPT, OBJ, FL_SOLVER_NEWTON, 1>(A, st); // fdd=Ldd (2074-2130)
+        if (method == FL_SOLVER_BFGS && A.exact_step > 0) return launch_k<NW, EPT, OBJ, FL_SOLVER_BFGS, 1, 1>(A, st);
         if (method == FL_SOLVER_BFGS) return launch_k<NW, EPT, OBJ, FL_SOLVER_BFGS, 1, 0>(A, st);
         return launch_k<NW, EPT, OBJ, FL_SOLVER_LBFGS, 1>(A, st);
     }

@@ -245,7 +245,7 @@ int fl_bfgs_update_gemm_batched(int batch, int n, double *H_dev, const double *s
  * C++ binding cpp/NonlinearOptimization.hpp:367-392) around solver = FL_SOLVER_LBFGS (NO.f90:2150-2167),
  * FL_SOLVER_CG (NO.f90:2168-2185), FL_SOLVER_BFGS (NO.f90:2131-2148: quasi-Newton with opt->exact_step <= 0, or with the
  * exact inverse Hessian of L every exact_step iterations) or FL_SOLVER_NEWTON (NO.f90:2074-2130); the last two take the
- * analytic Hessian of the augmented Lagrangian as the reference's Ldd forms it (NO.f90:2229-2241; n <= 2048).
+ * analytic Hessian of the augmented Lagrangian as the reference's Ldd forms it (NO.f90:2229-2241; every n of the fused path, n <= 4096).
  * Workspace as for the inner solver alone (fl_workspace_bytes_for).  Built-in constraint family: m block spheres
  * c_j(x) = sum_{i in block j} x_i^2 - 1 over m consecutive blocks of n/m elements (m = 1 is the unit
  * sphere of the reference's test, test/test.f90:699-721); m <= 16, n % m == 0.
@@ -417,7 +417,7 @@ int fl_rci_destroy(fl_rci *handle);
  * for the HESSIAN OF L (bit 4, FL_REQ_H = 16, at an unchanged point): the caller forms it as the reference's Ldd does
  * (NO.f90:2229-2241),  Ldd = f'' + sum_j c_j'' (miu c_j - lambda_j) + cd cd^T  -- lambda from lambda_dev, miu from
  * fl_rci_auglag_miu -- writes it with fl_rci_put_hessians (or into fl_rci_hessian_buffer) and steps again with the same f,
- * g, c, cd arrays; n <= 2048 for these two.  Without f'' / c'' the reference differentiates grad L by MKL's djacobi:
+ * g, c, cd arrays; n <= 4096 like every aug-Lagrangian handle.  Without f'' / c'' the reference differentiates grad L by MKL's djacobi:
  * fl_fd_points / fl_fd_column do that for a batch with djacobi's step rule (2n gradient evaluations per Hessian). */
 #define FL_RCI_REQ_C 32
 #define FL_RCI_REQ_CD 64

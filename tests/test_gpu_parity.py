@@ -675,6 +675,7 @@ def test_augmented_lagrangian_with_the_hessian_of_L_bitexact(solver_name, solver
     ("BFGS", O.DIAGQUAD, 64, 8, 64, {"Precision": 1e-8, "ExactStep": 5}),
     ("BFGS", O.ROSENBROCK, 96, 3, 16, {"Precision": 1e-7, "ExactStep": 3, "MaxIteration": 20}),
     ("NewtonRaphson", O.DIAGQUAD, 24, 3, 8, {"Precision": 1e-7, "numerical": True}),  # no fdd / cdd: djacobi's central differences of grad L
+    ("NewtonRaphson", O.DIAGQUAD, 2100, 4, 2, {"Precision": 1e-8, "MaxIteration": 2}),  # beyond n = 2048 (refused until round 4)
 ])
 def test_augmented_lagrangian_with_hessians_by_reverse_communication(solver_name, kind, n, m, B, kw):
     """AugmentedLagrangian around NewtonRaphson / BFGS(ExactStep > 0) with the CALLER's f, f', c, c', f'', c'' for a batch
@@ -799,12 +800,73 @@ def test_batched_newton_by_reverse_communication_with_analytic_and_numerical_hes
     assert float((xn - 1.0).abs().max()) < 1e-8
 
 
-def test_augmented_lagrangian_exact_inner_solvers_refuse_n_beyond_2048():
+@pytest.mark.parametrize("solver_name,solver,kind,n,m,kw", [
+    ("NewtonRaphson", 4, O.DIAGQUAD, 2100, 4, {"Precision": 1e-8, "MaxIteration": 2}),
+    ("NewtonRaphson", 4, O.ROSENBROCK, 2112, 3, {"Precision": 1e-7, "MaxIteration": 1}),
+    ("BFGS", O.BFGS, O.QUARTIC, 2100, 4, {"Precision": 1e-8, "ExactStep": 2, "MaxIteration": 2}),
+])
+def test_augmented_lagrangian_exact_inner_solvers_beyond_n_2048_bitexact(solver_name, solver, kind, n, m, kw):
+    """Until round 4 the fused aug-Lagrangian refused NewtonRaphson / exact-Hessian BFGS beyond n = 2048 (NO.f90:2074-2149 has
+    no such limit): the 8 waves x 8 elements kernels now exist for them too.  Held to the oracle bit for bit like the small
+    cases of test_augmented_lagrangian_with_the_hessian_of_L_bitexact -- a few outer rounds only: the oracle's Cholesky
+    replays the device's summation order one element at a time (n = 2100: ~25 s per factorisation on one core)."""
+    NLO = _nlo()
+    rng = np.random.default_rng(13 * n + m)
+    B = 2
+    i = np.arange(1, n + 1).astype(float)
+    x0 = 0.1 + 0.05 * np.cos(i)[None, :] + 0.01 * rng.standard_normal((B, n))
+    if kind == O.QUARTIC:
+        x0 = rng.random((B, n))
+    d = b = None
+    if kind == O.DIAGQUAD:
+        d, b = _quads(B, n, 2.0, 10.0, 5)
+    g = _gpu_auglag(solver_name, kind, x0, m, d, b, **kw)
+    T, E = NLO.reduction_geometry(n, 4 if solver == 4 else None)
+    assert (T, E) == (512, 8)
+    oo = _oracle_opts(O.BFGS if solver == O.BFGS else O.LBFGS, kw)
+    oo.exact_step = int(kw.get("ExactStep", 0))
+    O.lib().flo_set_auglag_bfgs_form(108)  # (the rank-2 updates are deferred in groups of 8 beyond n = 1024, like the kernels')
+    try:
+        o = O.auglag_batch(solver, kind, x0, m, d=d, b=b, opts=oo, sum_mode=O.TREE, threads=T, ept=E)
+    finally:
+        O.lib().flo_set_auglag_bfgs_form(0)
+    assert np.array_equal(g["outer"], o["outer"]), (g["outer"], o["outer"])
+    assert np.array_equal(g["iters"], o["iters"]), (g["iters"], o["iters"])
+    assert np.array_equal(g["nf"], o["nf"]) and np.array_equal(g["ng"], o["ng"])
+    assert np.array_equal(g["x"].view(np.uint64), o["x"].view(np.uint64))
+    assert np.array_equal(g["lambda"].view(np.uint64), o["lam"].view(np.uint64))
+    assert np.array_equal(g["cnorm2"].view(np.uint64), o["cnorm2"].view(np.uint64))
+
+
+@pytest.mark.parametrize("solver_name,kw", [("NewtonRaphson", {}), ("BFGS", {"ExactStep": 2})])
+def test_augmented_lagrangian_exact_inner_solvers_at_n_4096_return_to_the_constrained_minimum(solver_name, kw):
+    """... and at the register path's largest n, by what the answer must satisfy (no oracle at this size: one factorisation
+    takes it minutes).  L-BFGS finds the constrained minimum; NewtonRaphson / exact BFGS, started 0.1 % away from it with its
+    multipliers, must come back to it -- every Hessian of L, Cholesky factorisation and solve at n = 4096 has to be right for
+    that -- with the block spheres satisfied and grad L = 0.  (Few factorisations: one workgroup does each, ~1 s.)"""
     NLO = _nlo()
     dev = torch.device("cuda:0")
-    x = torch.zeros(1, 2560, dtype=torch.float64, device=dev)
-    with pytest.raises(Exception):
-        NLO.AugmentedLagrangian(O.QUARTIC, x, 4, UnconstrainedSolver="NewtonRaphson")
+    B, n, m = 2, 4096, 8
+    d, b = _quads(B, n, 2.0, 10.0, 7)
+    dd, bb = torch.tensor(d, device=dev), torch.tensor(b, device=dev)
+    x = torch.full((B, n), 0.02, dtype=torch.float64, device=dev)
+    ref = NLO.AugmentedLagrangian(O.DIAGQUAD, x, m, dd, bb, UnconstrainedSolver="LBFGS", Precision=1e-10, MaxIteration=100)
+    torch.cuda.synchronize()
+    xr, lam_r = x.cpu().numpy(), ref["lambda"].cpu().numpy()
+    w = n // m
+    assert np.abs((xr.reshape(B, m, w) ** 2).sum(2) - 1.0).max() < 1e-8
+    x2 = torch.tensor(xr * (1.0 + 1e-3 * np.cos(np.arange(n)))[None, :].repeat(B, 0).reshape(B, n), device=dev)
+    lam0 = torch.tensor(lam_r, device=dev)
+    out = NLO.AugmentedLagrangian(O.DIAGQUAD, x2, m, dd, bb, UnconstrainedSolver=solver_name, lambda0=lam0, miu0=10.0,
+                                  Precision=1e-9, MaxIteration=4, **kw)
+    torch.cuda.synchronize()
+    xs, lam = x2.cpu().numpy(), out["lambda"].cpu().numpy()
+    assert np.all(np.isfinite(xs)) and int(out["nf"].min()) > 0
+    assert np.abs(xs - xr).max() < 1e-7, np.abs(xs - xr).max()
+    c = (xs.reshape(B, m, w) ** 2).sum(2) - 1.0
+    assert np.abs(c).max() < 1e-6, np.abs(c).max()
+    gl = d * xs - b - (lam[:, :, None] * 2.0 * xs.reshape(B, m, w)).reshape(B, n)  # grad f - sum lambda_j grad c_j
+    assert np.abs(gl).max() < 1e-5, np.abs(gl).max()
 
 
 def test_rci_round_captured_in_a_hip_graph_walks_the_same_path():
