@@ -695,8 +695,10 @@ class CompiledObjective:
     """An objective given as HIP source text -- the functor of include/fl_user_objective.hpp:
         template <int NW, int EPT> struct Name { static constexpr int LDS_DOUBLES; init(A, prob, lds); eval(x, g, s0, s1, n, lds);
         static combine(s0, s1); } --
-    compiled into the fused kernel of `solver` (SD | CG | LBFGS_ | BFGS_) for dimension n (<= 4096) by hiprtc; .solve() then
-    runs batches at the fused kernel's speed.  tune_like: DIAGQUAD for an element-wise objective keeping at most two data
+    compiled into the fused kernel of `solver` (SD | CG | LBFGS_ | BFGS_) for dimension n by hiprtc; .solve() then
+    runs batches at the fused kernel's speed.  n > 4096 (vectors in HBM): class_name names a plain class with the STREAMING
+    interface instead -- NEIGHBOURS, init(A, prob), pair(e, n, x, xa, xb, ta, tb, ua, ub, ga, gb), combine(s0, s1):
+    include/fl_user_stream_objective.hpp, tests/user_sources.py STREAM_*.  tune_like: DIAGQUAD for an element-wise objective keeping at most two data
     vectors in registers, else TUNE_NONE.  The reference's interface for this is callbacks (NO.f90:33-38)."""
 
     def __init__(self, source, class_name, n, solver=LBFGS_, tune_like=TUNE_NONE, constrained=False, constraints_class=None):

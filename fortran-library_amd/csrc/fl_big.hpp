@@ -15,6 +15,37 @@
 
 namespace fl {
 
+// ---- the caller's own objective on this path (OBJ = FL_OBJ_USER): the STREAMING functor.  The register path's functor
+// (include/fl_user_objective.hpp: x and g as register arrays of the thread) has no meaning where the vectors live in HBM;
+// here the objective is asked one ELEMENT PAIR at a time, in the order the built-in ones are evaluated, and the solver does
+// the loads, the stores of g, the g.p / g.g terms and the fixed-order sums around it.  A plain class (no template
+// parameters), named by the macro FL_USER_STREAM_OBJECTIVE before this header is included (fl_user_compile does that for
+// n > 4096):
+//   static constexpr bool NEIGHBOURS;   true: pair() reads x of OTHER elements through its `x` argument (the row is complete
+//                                       and visible then: the trial point is stored in a pass of its own, a barrier follows)
+//   __device__ void init(const fl::SolveArgs &A, int prob);          once per problem (A.d / A.b / A.user: the caller's data)
+//   __device__ void pair(int e, int n, const double *x, double xa, double xb,   elements e (even) and e + 1 of problem `prob`
+//                        double &ta, double &tb, double &ua, double &ub, double &ga, double &gb);
+//        ta, tb: the elements' terms of the first sum s0; ua, ub: of the second sum s1; ga, gb: df/dx_e, df/dx_{e+1}.
+//        An element >= n is padding (its x is 0): whatever pair() returns for it is replaced by zeros.
+//   __device__ static double combine(double s0, double s1);          f from the two sums
+// The terms are added thread by thread in slot order, then over the workgroup in the fixed tree order -- for a functor that
+// restates a built-in objective, the built-in kernel's bits (tests/test_gpu_user_rtc.py).
+#ifdef FL_USER_STREAM_OBJECTIVE
+using BigUserObjective = FL_USER_STREAM_OBJECTIVE;
+#else
+struct BigUserObjective { // (placeholder: BigSolver<FL_OBJ_USER, .> is instantiated with a caller's class only)
+    static constexpr bool NEIGHBOURS = false;
+    __device__ void init(const SolveArgs &, int) {}
+    __device__ void pair(int, int, const double *, double, double, double &ta, double &tb, double &ua, double &ub, double &ga, double &gb)
+    {
+        ta = tb = ua = ub = ga = gb = 0.0;
+    }
+    __device__ static double combine(double s0, double) { return s0; }
+};
+#endif
+struct BigNoObjective {};
+
 template <int OBJ, int METHOD> struct BigSolver {
     static_assert(METHOD == FL_SOLVER_SD || METHOD == FL_SOLVER_CG || METHOD == FL_SOLVER_LBFGS ||
                       METHOD == FL_SOLVER_BFGS,
@@ -56,6 +87,9 @@ template <int OBJ, int METHOD> struct BigSolver {
     int main_it, h_valid, ndef, h_ident; // BFGS (names as in Solver)
     double a_id;
     LineSearch ls;
+    typename pick_type<OBJ == FL_OBJ_USER, BigUserObjective, BigNoObjective>::type uo; // the caller's streaming functor
+    static constexpr bool USER_NEIGHBOURS = OBJ == FL_OBJ_USER && BigUserObjective::NEIGHBOURS;
+    static constexpr bool X_BARRIERS = OBJ == FL_OBJ_ROSENBROCK || USER_NEIGHBOURS; // other threads' x is read
     enum { PH_INIT = 0, PH_LS = 1, PH_DONE = 2 };
     // COOPERATIVE form (reverse communication, few problems of very large n): G workgroups share one problem.  Workgroup
     // wg owns the slots c_lo <= c < c_hi of every thread (a contiguous range of ceil(nslot / G) slots), runs the same
@@ -242,6 +276,16 @@ template <int OBJ, int METHOD> struct BigSolver {
         a_id = 0.0;
         phase = PH_INIT;
         pending = 0;
+        if constexpr (OBJ == FL_OBJ_USER) uo.init(A, prob);
+    }
+    // the caller's terms for one element pair, padding forced to zero
+    __device__ __forceinline__ void user_pair(int e, double xa, double xb, double &ta, double &tb, double &ua, double &ub, double &ga, double &gb)
+    {
+        if constexpr (OBJ == FL_OBJ_USER) {
+            uo.pair(e, n, x, xa, xb, ta, tb, ua, ub, ga, gb);
+            if (e >= n) ta = ua = ga = 0.0;
+            if (e + 1 >= n) tb = ub = gb = 0.0;
+        }
     }
     __device__ __forceinline__ void clear_rows() // first launch: p = 0 like the register path, padding defined
     {
@@ -275,7 +319,7 @@ template <int OBJ, int METHOD> struct BigSolver {
     // built-in objective at the x in the user array: f, g (stored), g.p, g.g
     __device__ __forceinline__ void evaluate(double &f, double &gp, double &ggo)
     {
-        if constexpr (OBJ == FL_OBJ_ROSENBROCK) __syncthreads(); // neighbours' x are written
+        if constexpr (X_BARRIERS) __syncthreads(); // neighbours' x are written
         double r[4] = {0.0, 0.0, 0.0, 0.0};
         for (int c = c_lo; c < c_hi; ++c) {
             const int e = e_of(c);
@@ -318,6 +362,8 @@ template <int OBJ, int METHOD> struct BigSolver {
                 } else if (e + 1 == n - 1) {
                     gb = A_b;
                 }
+            } else if constexpr (OBJ == FL_OBJ_USER) {
+                user_pair(e, xa, xb, ta, tb, ua, ub, ga, gb);
             } else {
                 ta = tb = ga = gb = 0.0;
             }
@@ -325,20 +371,30 @@ template <int OBJ, int METHOD> struct BigSolver {
             double pa, pb;
             ldw(p, e, pa, pb);
             acc2(r[0], c, ta, tb);
-            if constexpr (OBJ == FL_OBJ_DIAGQUAD) acc2(r[1], c, ua, ub);
+            if constexpr (OBJ == FL_OBJ_DIAGQUAD || OBJ == FL_OBJ_USER) acc2(r[1], c, ua, ub);
             acc2(r[2], c, ga * pa, gb * pb);
             acc2(r[3], c, ga * ga, gb * gb);
         }
         reduce(r);
-        f = uni(Objective<OBJ, 1, 2>::combine(r[0], r[1]));
+        f = uni(combine_sums(r[0], r[1]));
         gp = uni(r[2]);
         ggo = uni(r[3]);
-        if constexpr (OBJ == FL_OBJ_ROSENBROCK) __syncthreads(); // all neighbour reads done before x moves again
+        if constexpr (X_BARRIERS) __syncthreads(); // all neighbour reads done before x moves again
+    }
+    __device__ __forceinline__ static double combine_sums(double s0, double s1)
+    {
+        if constexpr (OBJ == FL_OBJ_USER) return BigUserObjective::combine(s0, s1);
+        else return Objective<OBJ, 1, 2>::combine(s0, s1);
     }
     // a trial in ONE pass: x = x0 + at p formed, stored and evaluated together (Rosenbrock's neighbours are formed
     // from x0, p the same way -- bitwise the neighbour thread's x -- so no barrier is needed)
     __device__ __forceinline__ void move_evaluate(double at, double &f, double &gp, double &ggo)
     {
+        if constexpr (USER_NEIGHBOURS) { // (the caller's functor reads x itself: the trial point in a pass of its own)
+            move(at);
+            evaluate(f, gp, ggo);
+            return;
+        }
         if constexpr (OBJ == FL_OBJ_ROSENBROCK) __syncthreads(); // x0 / p rows of the neighbours are complete
         double r[4] = {0.0, 0.0, 0.0, 0.0};
         for (int c = c_lo; c < c_hi; ++c) {
@@ -385,17 +441,19 @@ template <int OBJ, int METHOD> struct BigSolver {
                 } else if (e + 1 == n - 1) {
                     gb = A_b;
                 }
+            } else if constexpr (OBJ == FL_OBJ_USER) {
+                user_pair(e, xa, xb, ta, tb, ua, ub, ga, gb);
             } else {
                 ta = tb = ga = gb = 0.0;
             }
             stw(g, e, ga, gb);
             acc2(r[0], c, ta, tb);
-            if constexpr (OBJ == FL_OBJ_DIAGQUAD) acc2(r[1], c, ua, ub);
+            if constexpr (OBJ == FL_OBJ_DIAGQUAD || OBJ == FL_OBJ_USER) acc2(r[1], c, ua, ub);
             acc2(r[2], c, ga * pa, gb * pb);
             acc2(r[3], c, ga * ga, gb * gb);
         }
         reduce(r);
-        f = uni(Objective<OBJ, 1, 2>::combine(r[0], r[1]));
+        f = uni(combine_sums(r[0], r[1]));
         gp = uni(r[2]);
         ggo = uni(r[3]);
     }
@@ -992,5 +1050,29 @@ template <int OBJ, int METHOD> struct BigSolver {
         }
     }
 };
+
+// n > 4096: vectors in HBM, one workgroup of 1024 threads per problem (fl_big.hpp)
+template <int OBJ, int METHOD> __global__ __launch_bounds__(1024) void fl_big_solve_kernel(SolveArgs A, double *rows)
+{
+    using S = BigSolver<OBJ, METHOD>;
+    __shared__ __attribute__((aligned(16))) double lds[S::LDS_TOTAL];
+    S s(A, lds, rows);
+    s.init();
+    s.clear_rows();
+    int rq = s.start();
+    double fv = 0.0, pv = 0.0, gg = 0.0;
+    while (rq) {
+        if (!(rq & FL_REQ_SAME)) {
+            if (rq & FL_REQ_NOMOVE) s.evaluate(fv, pv, gg);
+            else s.move_evaluate(s.request_point(), fv, pv, gg); // the trial point is formed and evaluated in one pass
+        }
+        if (s.must_stop(fv)) { // (see Solver::must_stop)
+            s.stop_not_finite();
+            break;
+        }
+        rq = s.advance(fv, pv, gg);
+    }
+    s.finish();
+}
 
 } // namespace fl

@@ -20,29 +20,7 @@
 
 namespace fl {
 
-// n > 4096: vectors in HBM, one workgroup of 1024 threads per problem (fl_big.hpp)
-template <int OBJ, int METHOD> __global__ __launch_bounds__(1024) void fl_big_solve_kernel(SolveArgs A, double *rows)
-{
-    using S = BigSolver<OBJ, METHOD>;
-    __shared__ __attribute__((aligned(16))) double lds[S::LDS_TOTAL];
-    S s(A, lds, rows);
-    s.init();
-    s.clear_rows();
-    int rq = s.start();
-    double fv = 0.0, pv = 0.0, gg = 0.0;
-    while (rq) {
-        if (!(rq & FL_REQ_SAME)) {
-            if (rq & FL_REQ_NOMOVE) s.evaluate(fv, pv, gg);
-            else s.move_evaluate(s.request_point(), fv, pv, gg); // the trial point is formed and evaluated in one pass
-        }
-        if (s.must_stop(fv)) { // (see Solver::must_stop)
-            s.stop_not_finite();
-            break;
-        }
-        rq = s.advance(fv, pv, gg);
-    }
-    s.finish();
-}
+// n > 4096: vectors in HBM, one workgroup of 1024 threads per problem (fl_big.hpp: fl_big_solve_kernel)
 template <int OBJ> static hipError_t launch_big_m(int method, const SolveArgs &A, double *rows, hipStream_t st)
 {
 #define FL_BIG(M) hipLaunchKernelGGL((fl_big_solve_kernel<OBJ, M>), dim3(A.batch), dim3(1024), 0, st, A, rows)

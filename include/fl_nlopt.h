@@ -284,7 +284,19 @@ int fl_augmented_lagrangian_launch_plan(int solver, int objective, int batch, in
  * embedded in libFL.so, libhiprtc.so is opened on first use -- and fl_user_solve runs a batch with it: the fused kernel's
  * speed (the reverse-communication form is 22 x slower on the headline workload), its geometry and summation order -- a
  * functor restating a built-in objective reproduces it bit for bit.
- *   solver     FL_SOLVER_SD | CG | LBFGS | BFGS (quasi-Newton updates: exact_step is taken as 0); n <= 4096
+ *   solver     FL_SOLVER_SD | CG | LBFGS | BFGS (quasi-Newton updates: exact_step is taken as 0)
+ *   n          <= 4096: the class template above.  n > 4096 (the vectors live in HBM, 1024 threads per problem): class_name
+ *              names a plain class with the STREAMING interface -- the objective is asked one element pair at a time, the
+ *              solver does the loads, stores and fixed-order sums around it (include/fl_user_stream_objective.hpp):
+ *                  struct <class_name> {
+ *                      static constexpr bool NEIGHBOURS = ...;      // pair() reads x of other elements through `x`
+ *                      __device__ void init(const fl::SolveArgs &A, int prob);
+ *                      __device__ void pair(int e, int n, const double *x, double xa, double xb,   // elements e (even), e + 1
+ *                                           double &ta, double &tb, double &ua, double &ub, double &ga, double &gb);
+ *                      __device__ static double combine(double s0, double s1);   // s0 = sum of ta, tb; s1 = sum of ua, ub
+ *                  };
+ *              SD / CG / L-BFGS at any n, BFGS up to n = 16384 (its dense H); tune_like is not used; not inside the
+ *              augmented Lagrangian.  A class restating a built-in objective reproduces the built-in kernel bit for bit here too.
  *   tune_like  whose register budget the kernel is tuned like: FL_OBJ_DIAGQUAD for an element-wise objective with at most two
  *              data vectors in registers, FL_OBJ_USER_TUNE_NONE (4) when in doubt (no occupancy caps: nothing can spill)
  *   log        (may be NULL) receives the compiler's messages, truncated to log_bytes

@@ -26,12 +26,16 @@ def test_install_lays_out_the_references_artefacts(prefix):
     for rel in ("lib/libFL.so", "lib/libFL.a", "include/fl_nlopt.h", "include/fl_legacy.h", "include/fl_user_objective.hpp",
                 "include/FortranLibrary.hpp", "include/NonlinearOptimization.hpp", "include/nonlinearoptimization.mod",
                 "include/fortranlibrary.mod", "include/NonlinearOptimization.f90", "include/FortranLibrary.f90",
-                "include/fl/fl_solver_launch.hpp", "include/fl/fl_device.hpp", "FortranLibrary/__init__.py",
+                "include/fl/fl_solver_launch.hpp", "include/fl/fl_device.hpp", "include/fl/fl_big.hpp",
+                "include/fl_user_stream_objective.hpp", "FortranLibrary/__init__.py",
                 "FortranLibrary/NonlinearOptimization.py"):
         assert (prefix / rel).exists(), rel
     # nothing in the installed headers reaches back into the source tree
     for f in (prefix / "include").rglob("*.h*"):
-        assert "fortran-library_amd/csrc" not in f.read_text().replace('#include "../fortran-library_amd/csrc/fl_solver_launch.hpp"', ""), f
+        text = f.read_text()
+        for fallback in ("fl_solver_launch.hpp", "fl_big.hpp"):  # (the source-tree branch of the __has_include pair)
+            text = text.replace('#include "../fortran-library_amd/csrc/%s"' % fallback, "")
+        assert "fortran-library_amd/csrc" not in text, f
 
 
 def test_a_callers_hip_objective_compiles_against_the_installed_headers_alone(prefix, tmp_path):
@@ -42,6 +46,15 @@ def test_a_callers_hip_objective_compiles_against_the_installed_headers_alone(pr
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", f"-I{prefix}/include", str(src),
                            f"-L{prefix}/lib", "-lFL", f"-Wl,-rpath,{prefix}/lib", "-o", str(out)], cwd=tmp_path)
     assert out.exists()
+    # ... and the streaming form for n > 4096 (fl_user_stream_objective.hpp, included twice around the class)
+    src2 = tmp_path / "caller_stream.hip"
+    text = open(os.path.join(ROOT, "tests", "user_stream_objective_caller.hip")).read()
+    assert text.count('#include "../include/fl_user_stream_objective.hpp"') == 2
+    src2.write_text(text.replace('#include "../include/fl_user_stream_objective.hpp"', '#include "fl_user_stream_objective.hpp"'))
+    out2 = tmp_path / "caller_stream"
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", f"-I{prefix}/include", str(src2),
+                           f"-L{prefix}/lib", "-lFL", f"-Wl,-rpath,{prefix}/lib", "-o", str(out2)], cwd=tmp_path)
+    assert out2.exists()
 
 
 def test_a_c_program_links_the_static_library(prefix, tmp_path):

@@ -20,7 +20,10 @@ def _nlo():
 @pytest.mark.parametrize("name,src,cls,solver,n,tune", [
     ("quadratic L-BFGS 2x8", US.DIAGQUAD, "MyQuadratic", 2, 1024, 2), ("quadratic CG 1x16", US.DIAGQUAD, "MyQuadratic", 1, 1024, 2),
     ("quadratic SD 1x8", US.DIAGQUAD, "MyQuadratic", 0, 300, 2), ("quadratic BFGS 1x4", US.DIAGQUAD, "MyQuadratic", 3, 256, 2),
-    ("Rosenbrock L-BFGS 1x4", US.ROSENBROCK, "MyRosenbrock", 2, 256, 4), ("Rosenbrock L-BFGS 8x8", US.ROSENBROCK, "MyRosenbrock", 2, 4096, 4)])
+    ("Rosenbrock L-BFGS 1x4", US.ROSENBROCK, "MyRosenbrock", 2, 256, 4), ("Rosenbrock L-BFGS 8x8", US.ROSENBROCK, "MyRosenbrock", 2, 4096, 4),
+    # n > 4096: the streaming functor in the vectors-in-HBM kernel
+    ("stream quadratic L-BFGS", US.STREAM_DIAGQUAD, "MyBigQuadratic", 2, 5000, 4), ("stream quadratic BFGS", US.STREAM_DIAGQUAD, "MyBigQuadratic", 3, 6001, 4),
+    ("stream Rosenbrock CG", US.STREAM_ROSENBROCK, "MyBigRosenbrock", 1, 100000, 4), ("stream Rosenbrock SD", US.STREAM_ROSENBROCK, "MyBigRosenbrock", 0, 4097, 4)])
 def test_objective_sources_compile_for_gfx950_without_a_gpu(name, src, cls, solver, n, tune):
     rc, log = _nlo().compile_check(src, cls, n, solver, tune)
     assert rc == 0, (name, log[:2000])
@@ -30,7 +33,8 @@ def test_a_source_that_does_not_compile_is_reported_with_the_compilers_message()
     NLO = _nlo()
     rc, log = NLO.compile_check(US.BROKEN, "Oops", 256)
     assert rc == -1 and "undeclared_name" in log and "objective:" in log, log[:1000]
-    assert NLO.compile_check(US.DIAGQUAD, "MyQuadratic", 5000)[0] == -2      # beyond the register path
+    assert NLO.compile_check(US.DIAGQUAD, "MyQuadratic", 5000)[0] == -1      # beyond the register path: the streaming functor's interface
+    assert NLO.compile_check(US.STREAM_DIAGQUAD, "MyBigQuadratic", 20000, solver=3)[0] == -2  # dense BFGS: H up to n = 16384
     assert NLO.compile_check(US.DIAGQUAD, "MyQuadratic", 256, solver=4)[0] == -1  # NewtonRaphson needs a Hessian functor
     assert NLO.compile_check(US.DIAGQUAD, "NoSuchClass", 256)[0] == -1
 

@@ -161,3 +161,64 @@ template <int NW, int EPT> struct MyStrideSums {
     }
 };
 """
+
+# ---- n > 4096: the STREAMING functor (fortran-library_amd/csrc/fl_big.hpp): a plain class asked one element pair at a time
+# the diagonal quadratic again (data0 = d, data1 = b), restating the built-in vectors-in-HBM kernel's arithmetic
+STREAM_DIAGQUAD = r"""
+struct MyBigQuadratic {
+    static constexpr bool NEIGHBOURS = false;
+    const double *d, *b;
+    __device__ void init(const fl::SolveArgs &A, int prob)
+    {
+        d = A.d + (size_t)prob * A.n;
+        b = A.b + (size_t)prob * A.n;
+    }
+    __device__ void pair(int e, int n, const double *, double xa, double xb, double &ta, double &tb, double &ua, double &ub,
+                         double &ga, double &gb)
+    {
+        const double da = e < n ? d[e] : 0.0, db = e + 1 < n ? d[e + 1] : 0.0;
+        const double ba = e < n ? b[e] : 0.0, bb = e + 1 < n ? b[e + 1] : 0.0;
+        const double dxa = da * xa, dxb = db * xb;
+        ta = dxa * xa;
+        tb = dxb * xb;
+        ua = ba * xa;
+        ub = bb * xb;
+        ga = dxa - ba;
+        gb = dxb - bb;
+    }
+    __device__ static double combine(double s0, double s1) { return 0.5 * s0 - s1; }
+};
+"""
+
+# chained Rosenbrock: NEIGHBOUR-COUPLED -- pair() reads x[e-1] and x[e+2] from the row (NEIGHBOURS = true: the trial point is
+# stored in a pass of its own and a barrier precedes the evaluation)
+STREAM_ROSENBROCK = r"""
+struct MyBigRosenbrock {
+    static constexpr bool NEIGHBOURS = true;
+    __device__ void init(const fl::SolveArgs &, int) {}
+    __device__ void pair(int e, int n, const double *x, double xa, double xb, double &ta, double &tb, double &ua, double &ub,
+                         double &ga, double &gb)
+    {
+        const double xl = (e >= 1 && e - 1 < n) ? x[e - 1] : 0.0;
+        const double xr = (e + 2 < n) ? x[e + 2] : 0.0;
+        const double ul = xa - xl * xl, um = xb - xa * xa, ur = xr - xb * xb;
+        const double va = 1.0 - xa, vb = 1.0 - xb;
+        const double A_a = (e >= 1) ? 200.0 * ul : 0.0;
+        const double A_b = 200.0 * um;
+        ta = tb = ga = gb = ua = ub = 0.0;
+        if (e <= n - 2) {
+            ta = 100.0 * (um * um) + va * va;
+            ga = A_a - 400.0 * xa * um - 2.0 * va;
+        } else if (e == n - 1) {
+            ga = A_a;
+        }
+        if (e + 1 <= n - 2) {
+            tb = 100.0 * (ur * ur) + vb * vb;
+            gb = A_b - 400.0 * xb * ur - 2.0 * vb;
+        } else if (e + 1 == n - 1) {
+            gb = A_b;
+        }
+    }
+    __device__ static double combine(double s0, double) { return s0; }
+};
+"""
