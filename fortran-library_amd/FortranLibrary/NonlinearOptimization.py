@@ -777,6 +777,13 @@ def compile_check(source, class_name, n, solver=LBFGS_, tune_like=TUNE_NONE, arc
 
 
 FL.fl_augmented_lagrangian_launch_plan.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
+FL.fl_cooperative_groups_for.argtypes = [C.c_int] * 4
+
+
+def cooperative_groups(solver, objective, batch, n):
+    """workgroups that share one problem when SteepestDescent / ConjugateGradient / LBFGS run this batch on the current device
+    (1: none; > 1 for few problems of n > 14336: the sums are then the oracle's tree order with `groups`; FL_COOP_GROUPS overrides)"""
+    return int(FL.fl_cooperative_groups_for(int(solver), int(objective), int(batch), int(n)))
 
 
 def augmented_lagrangian_launch_plan(solver, objective, batch, n, M):

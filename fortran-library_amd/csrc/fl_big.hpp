@@ -66,7 +66,10 @@ template <int OBJ, int METHOD> struct BigSolver {
     // cooperative form (reverse communication only): the partial sums of up to COOP_MAX_GROUPS workgroups, staged for the
     // left-to-right addition
     static constexpr int COOP_MAX_GROUPS = 256;
-    static constexpr int LDS_TOTAL = L_COOP + (OBJ == FL_OBJ_EXTERNAL && METHOD != FL_SOLVER_BFGS ? COOP_MAX_GROUPS * Reducer<16>::NVMAX : 0);
+    static constexpr int LDS_TOTAL = L_COOP + (METHOD != FL_SOLVER_BFGS ? COOP_MAX_GROUPS * Reducer<16>::NVMAX : 0);
+    // the cooperative form needs every element touched by its owner alone: not BFGS (the dense H is folded across rows), not an
+    // objective that reads its neighbours' x (written by another workgroup, possibly behind another XCD's L2)
+    static constexpr bool COOP_OK = METHOD != FL_SOLVER_BFGS && !(OBJ == FL_OBJ_ROSENBROCK || (OBJ == FL_OBJ_USER && BigUserObjective::NEIGHBOURS));
     static constexpr int RCI_SCALARS = 48;
     static constexpr int UNI_LEVEL = (METHOD == FL_SOLVER_BFGS) ? 2 : FL_UNI_LEVEL; // 128 VGPRs per wave: BFGS pins the search to SGPRs
 
@@ -1041,6 +1044,9 @@ template <int OBJ, int METHOD> struct BigSolver {
     __device__ __forceinline__ void finish() // x already holds the last evaluated point
     {
         if (tid == 0 && wg == 0) {
+            // (fused cooperative form: a barrier that gave up waiting -- the problem's workgroups were not resident together --
+            // leaves sums that mean nothing: the problem is reported as not solved)
+            if (G > 1 && __hip_atomic_load(coop_counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) status = FL_STATUS_NOT_SOLVED;
             if (A.f_out) A.f_out[prob] = fnew;
             if (A.gg_out) A.gg_out[prob] = gg;
             if (A.iters) A.iters[prob] = iters;
@@ -1051,12 +1057,26 @@ template <int OBJ, int METHOD> struct BigSolver {
     }
 };
 
-// n > 4096: vectors in HBM, one workgroup of 1024 threads per problem (fl_big.hpp)
-template <int OBJ, int METHOD> __global__ __launch_bounds__(1024) void fl_big_solve_kernel(SolveArgs A, double *rows)
+// n > 4096: vectors in HBM, one workgroup of 1024 threads per problem.
+// groups > 1: the COOPERATIVE form of the fused solve (round 4) -- `groups` workgroups share one problem: blockIdx.x = problem *
+// groups + group, each owns a contiguous range of every thread's slots, all run the same scalar machine and meet in every
+// reduction (BigSolver::reduce: partial sums + a grid barrier of the problem's workgroups).  For FEW problems of very large n
+// -- the reference's callers typically solve one problem of any dim -- which otherwise occupy one CU each: the whole solve stays
+// one launch, a trial costs its HBM traffic at the chip's bandwidth plus one barrier.  The sums are those of the oracle's tree
+// order with `groups` (fl_cooperative_groups_for reports it).  The host sizes the grid so that all workgroups are resident
+// (occupancy query); should they not be, the barrier's bounded wait ends and the problem reports FL_STATUS_NOT_SOLVED.
+template <int OBJ, int METHOD>
+__global__ __launch_bounds__(1024) void fl_big_solve_kernel(SolveArgs A, double *rows, int groups, double *coop_part, unsigned *coop_counter)
 {
     using S = BigSolver<OBJ, METHOD>;
     __shared__ __attribute__((aligned(16))) double lds[S::LDS_TOTAL];
-    S s(A, lds, rows);
+    const int prob = groups > 1 ? (int)blockIdx.x / groups : (int)blockIdx.x;
+    S s(A, lds, rows, prob);
+    if constexpr (S::COOP_OK) {
+        if (groups > 1)
+            s.set_cooperative(groups, (int)blockIdx.x - prob * groups, coop_part + (size_t)prob * 2 * groups * Reducer<S::NW>::NVMAX,
+                              coop_counter + 2 * prob);
+    }
     s.init();
     s.clear_rows();
     int rq = s.start();

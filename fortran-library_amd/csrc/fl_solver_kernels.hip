@@ -15,31 +15,88 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 
 
 
 namespace fl {
 
-// n > 4096: vectors in HBM, one workgroup of 1024 threads per problem (fl_big.hpp: fl_big_solve_kernel)
-template <int OBJ> static hipError_t launch_big_m(int method, const SolveArgs &A, double *rows, hipStream_t st)
+static int device_compute_units();
+
+// n > 4096: vectors in HBM, one workgroup of 1024 threads per problem (fl_big.hpp: fl_big_solve_kernel) -- or, for few
+// problems, `groups` workgroups per problem (the cooperative form)
+template <int OBJ, int M> static hipError_t launch_big_k(const SolveArgs &A, double *rows, int groups, double *part, unsigned *counter, hipStream_t st)
 {
-#define FL_BIG(M) hipLaunchKernelGGL((fl_big_solve_kernel<OBJ, M>), dim3(A.batch), dim3(1024), 0, st, A, rows)
-    switch (method) {
-    case FL_SOLVER_SD: FL_BIG(FL_SOLVER_SD); break;
-    case FL_SOLVER_CG: FL_BIG(FL_SOLVER_CG); break;
-    case FL_SOLVER_BFGS: FL_BIG(FL_SOLVER_BFGS); break;
-    default: FL_BIG(FL_SOLVER_LBFGS); break;
-    }
-#undef FL_BIG
+    hipLaunchKernelGGL((fl_big_solve_kernel<OBJ, M>), dim3(A.batch * (groups > 1 ? groups : 1)), dim3(1024), 0, st, A, rows, groups, part, counter);
     return hipGetLastError();
 }
-static hipError_t launch_big(int obj, int method, const SolveArgs &A, double *rows, hipStream_t st)
+template <int OBJ, int M> static int big_per_cu()
+{
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fl_big_solve_kernel<OBJ, M>, 1024, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        per_cu = 0;
+    }
+    return per_cu;
+}
+// op 0: launch; op 1: workgroups of this kernel that fit one CU (the occupancy query)
+template <int OBJ> static int big_dispatch_m(int op, int method, const SolveArgs *A, double *rows, int groups, double *part, unsigned *counter, hipStream_t st)
+{
+    switch (method) {
+    case FL_SOLVER_SD: return op ? big_per_cu<OBJ, FL_SOLVER_SD>() : (int)launch_big_k<OBJ, FL_SOLVER_SD>(*A, rows, groups, part, counter, st);
+    case FL_SOLVER_CG: return op ? big_per_cu<OBJ, FL_SOLVER_CG>() : (int)launch_big_k<OBJ, FL_SOLVER_CG>(*A, rows, groups, part, counter, st);
+    case FL_SOLVER_BFGS: return op ? big_per_cu<OBJ, FL_SOLVER_BFGS>() : (int)launch_big_k<OBJ, FL_SOLVER_BFGS>(*A, rows, groups, part, counter, st);
+    default: return op ? big_per_cu<OBJ, FL_SOLVER_LBFGS>() : (int)launch_big_k<OBJ, FL_SOLVER_LBFGS>(*A, rows, groups, part, counter, st);
+    }
+}
+static int big_dispatch(int op, int obj, int method, const SolveArgs *A, double *rows, int groups, double *part, unsigned *counter, hipStream_t st)
 {
     switch (obj) {
-    case FL_OBJ_QUARTIC: return launch_big_m<FL_OBJ_QUARTIC>(method, A, rows, st);
-    case FL_OBJ_ROSENBROCK: return launch_big_m<FL_OBJ_ROSENBROCK>(method, A, rows, st);
-    default: return launch_big_m<FL_OBJ_DIAGQUAD>(method, A, rows, st);
+    case FL_OBJ_QUARTIC: return big_dispatch_m<FL_OBJ_QUARTIC>(op, method, A, rows, groups, part, counter, st);
+    case FL_OBJ_ROSENBROCK: return big_dispatch_m<FL_OBJ_ROSENBROCK>(op, method, A, rows, groups, part, counter, st);
+    default: return big_dispatch_m<FL_OBJ_DIAGQUAD>(op, method, A, rows, groups, part, counter, st);
     }
+}
+// Workgroups per problem for a fused solve beyond n = 4096 (fl_cooperative_groups_for).  More than one where the chip would
+// otherwise stand mostly idle: every workgroup must be RESIDENT (the barriers spin) -- CUs x what the occupancy query says fits
+// one CU (capped at one: a sibling on the same CU would share its LDS pipe for nothing) / batch -- and own at least two slots of
+// every thread; not below 8 slots per thread (n <= 14336: little to share out, and the sums' order -- with it the result's last
+// bits -- would change for sizes where it buys next to nothing).  FL_COOP_GROUPS in the environment overrides (1: never).
+int big_cooperative_groups(int method, int objective, int batch, int n, bool coop_ok, int per_cu)
+{
+    using BS = BigSolver<FL_OBJ_QUARTIC, FL_SOLVER_SD>;
+    if (!coop_ok || n <= 4096 || batch <= 0) return 1;
+    int cus = device_compute_units();
+    if (cus > BS::COOP_MAX_GROUPS) cus = BS::COOP_MAX_GROUPS;
+    if (per_cu < 1) return 1;
+    const int nslot = BS::slots_for(n);
+    int want = cus / batch;
+    if (want > nslot / 2) want = nslot / 2;
+    // (beyond 64 the barrier outweighs the bandwidth: thread 0's poll, G partial sums to fetch and add left to right per
+    // reduction -- one problem of n = 2^20, L-BFGS: 1 / 8 / 32 / 64 / 128 / 256 workgroups 1135 / 152 / 51 / 40.5 / 48.6 / 73.6 ms)
+    if (want > 64) want = 64;
+    if (nslot < 8) want = 1;
+    if (const char *e = std::getenv("FL_COOP_GROUPS")) {
+        want = std::atoi(e);
+        if (want > cus / batch) want = cus / batch;
+        if (want > nslot) want = nslot;
+    }
+    return want > 1 ? BS::coop_groups(n, want) : 1;
+}
+// the launch itself with the cooperative form's scratch (partial sums, arrival counters) from the stream-ordered allocator
+hipError_t launch_big_with_groups(int groups, int batch, hipStream_t st, const std::function<hipError_t(int, double *, unsigned *)> &launch)
+{
+    if (groups <= 1) return launch(1, nullptr, nullptr);
+    const size_t part_bytes = (size_t)batch * 2 * groups * Reducer<16>::NVMAX * sizeof(double), cnt_bytes = (size_t)batch * 2 * sizeof(unsigned);
+    char *scr = nullptr;
+    if (hipMallocAsync((void **)&scr, part_bytes + cnt_bytes, st) != hipSuccess) {
+        (void)hipGetLastError();
+        return launch(1, nullptr, nullptr); // (no scratch: one workgroup per problem as ever)
+    }
+    hipError_t e = hipMemsetAsync(scr + part_bytes, 0, cnt_bytes, st);
+    if (e == hipSuccess) e = launch(groups, reinterpret_cast<double *>(scr), reinterpret_cast<unsigned *>(scr + part_bytes));
+    const hipError_t ef = hipFreeAsync(scr, st);
+    return e == hipSuccess ? ef : e;
 }
 
 // ------------------------------------------------------------ host dispatch
@@ -280,7 +337,11 @@ static int solve(int method, int objective, int batch, int n, double *x, const d
             (void)hipGetLastError(); // the failed allocation must not taint the caller's next call
             return FL_ERR_WORKSPACE;
         }
-        hipError_t e = launch_big(objective, method, A, rows, st);
+        const bool coop_ok = method != FL_SOLVER_BFGS && objective != FL_OBJ_ROSENBROCK;
+        const int groups = big_cooperative_groups(method, objective, batch, n, coop_ok, coop_ok ? big_dispatch(1, objective, method, nullptr, nullptr, 1, nullptr, nullptr, st) : 0);
+        hipError_t e = launch_big_with_groups(groups, batch, st, [&](int G, double *part, unsigned *counter) {
+            return (hipError_t)big_dispatch(0, objective, method, &A, rows, G, part, counter, st);
+        });
         if (own_rows) { // stream-ordered: the rows are released once the kernel above has finished
             const hipError_t ef = hipFreeAsync(rows, st);
             if (e == hipSuccess) e = ef;
@@ -439,6 +500,17 @@ int fl_reduction_geometry(int n, int *threads, int *ept)
     if (threads) *threads = g.nw * 64;
     if (ept) *ept = g.ept;
     return FL_OK;
+}
+
+// workgroups that share one problem in the fused solve of this batch on the current device (1: none; > 1: the cooperative
+// form of the vectors-in-HBM path, whose sums are those of the oracle's tree order with `groups`)
+int fl_cooperative_groups_for(int solver, int objective, int batch, int n)
+{
+    if (n <= 4096 || batch <= 0 || objective < FL_OBJ_QUARTIC || objective > FL_OBJ_DIAGQUAD) return 1;
+    if (solver != FL_SOLVER_SD && solver != FL_SOLVER_CG && solver != FL_SOLVER_LBFGS) return 1;
+    const bool coop_ok = objective != FL_OBJ_ROSENBROCK;
+    return fl::big_cooperative_groups(solver, objective, batch, n, coop_ok,
+                                      coop_ok ? fl::big_dispatch(1, objective, solver, nullptr, nullptr, 1, nullptr, nullptr, nullptr) : 0);
 }
 
 int fl_reduction_geometry_for(int solver, int n, int *threads, int *ept)

@@ -267,6 +267,11 @@ module NonlinearOptimization
             import
             type(c_ptr),value::handle
         end function fl_user_destroy
+        !workgroups that share one problem of this batch in the fused solvers (n > 14336, few problems; 1: none)
+        integer(c_int) function fl_cooperative_groups_for(solver,objective,batch,n) bind(C,name='fl_cooperative_groups_for')
+            import
+            integer(c_int),value::solver,objective,batch,n
+        end function fl_cooperative_groups_for
     end interface
 
 contains

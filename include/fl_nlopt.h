@@ -62,8 +62,9 @@ extern "C" {
 #define FL_STATUS_STALLED 5        /* fused kernels: the line search's zoom did not narrow its bracket in 65 536 consecutive  */
                                    /* trials -- the reference's zoom has no iteration limit and never returns on such a      */
                                    /* problem (NO.f90:1557-1579); the problem stops at the last trial point                  */
-#define FL_STATUS_NOT_SOLVED (-1)  /* fl_multi_solve only: the shard holding this problem failed (allocation, launch); */
-                                   /* its rows of x and of the outputs are untouched                                  */
+#define FL_STATUS_NOT_SOLVED (-1)  /* fl_multi_solve: the shard holding this problem failed (allocation, launch): its rows of x */
+                                   /* and of the outputs are untouched; cooperative form (fl_cooperative_groups_for): the       */
+                                   /* problem's workgroups were not resident together, x and the outputs mean nothing           */
 
 #define FL_CG_DY 0 /* Dai-Yuan        NO.f90:352-372 */
 #define FL_CG_PR 1 /* Polak-Ribiere+  NO.f90:373-393 */
@@ -117,6 +118,15 @@ int fl_reduction_geometry(int n, int *threads, int *ept);
  * history to keep, the state fits) and FL_SOLVER_NEWTON 256 < n <= 512 with two waves x 4 (its Cholesky wants the threads).  threads*ept -- the padded length of every workspace row -- is the same for all solvers of
  * an n; the reverse-communication kernels (fl_rci_*) and the dense routines use fl_reduction_geometry's. */
 int fl_reduction_geometry_for(int solver, int n, int *threads, int *ept);
+/* FEW problems of very large n (the reference's callers typically solve ONE problem of any dim): beyond n = 14336 and below one
+ * problem per two compute units, fl_steepest_descent_batched / fl_conjugate_gradient_batched / fl_lbfgs_batched (objectives
+ * FL_OBJ_QUARTIC, FL_OBJ_DIAGQUAD) and fl_user_solve (a streaming functor without NEIGHBOURS) share each problem among `groups`
+ * workgroups -- one launch for the whole solve, a line-search trial at the chip's bandwidth instead of one CU's.  Each
+ * workgroup owns a contiguous range of every thread's elements; every sum is then: the workgroups' sums in the usual order,
+ * added left to right -- so the last bits of a result depend on `groups`, which this call reports for a batch on the
+ * current device (1: none).  FL_COOP_GROUPS=<g> in the environment overrides the choice (1: never).  A problem whose
+ * workgroups could not all be resident ends with FL_STATUS_NOT_SOLVED (the device was shared with other work). */
+int fl_cooperative_groups_for(int solver, int objective, int batch, int n);
 
 /* The fused L-BFGS kernel keeps the newest pairs of its (s, y) ring on the chip (registers, then an LDS ring); this
  * returns how many for a built-in objective and dimension n (0 beyond n = 4096).  With C of them on the chip an

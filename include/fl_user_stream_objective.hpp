@@ -31,7 +31,9 @@
 // Solvers: FL_SOLVER_SD, FL_SOLVER_CG, FL_SOLVER_LBFGS (any n > 4096), FL_SOLVER_BFGS (quasi-Newton updates, n <= 16384).
 // Summation order: thread t adds the terms of its pairs (c * 1024 + t) * 2, c = 0, 1, ..., then the workgroup's fixed tree
 // (fl_reduction_geometry reports 1024 threads x 2 * slots): bit for bit reproducible, replayable by the oracle.
-// Compile with hipcc --offload-arch=gfx950 -ffp-contract=off, link with libFL.so.
+// One workgroup per problem here (the cooperative form -- several workgroups per problem for few huge problems -- is chosen
+// by the library's own entries: fl_*_batched and fl_user_solve).  Compile with hipcc --offload-arch=gfx950 -ffp-contract=off,
+// link with libFL.so.
 #ifndef FL_USER_STREAM_OBJECTIVE_TYPES
 #define FL_USER_STREAM_OBJECTIVE_TYPES
 #if __has_include("fl/fl_solver_launch.hpp") // installed layout: prefix/include/fl/ (make install)
@@ -87,7 +89,7 @@ inline int solve_stream(int solver, int batch, int n, double *x_dev, const doubl
         (void)hipGetLastError();
         return FL_ERR_WORKSPACE;
     }
-#define FL_STREAM_K(M) hipLaunchKernelGGL((fl_big_solve_kernel<FL_OBJ_USER, M>), dim3(batch), dim3(1024), 0, stream, A, rows)
+#define FL_STREAM_K(M) hipLaunchKernelGGL((fl_big_solve_kernel<FL_OBJ_USER, M>), dim3(batch), dim3(1024), 0, stream, A, rows, 1, (double *)nullptr, (unsigned *)nullptr)
     switch (solver) {
     case FL_SOLVER_SD: FL_STREAM_K(FL_SOLVER_SD); break;
     case FL_SOLVER_CG: FL_STREAM_K(FL_SOLVER_CG); break;
