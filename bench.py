@@ -952,6 +952,64 @@ def rtc_leg(ctx, NLO):
             "same_bits_as_builtin": same, "note": "timed with the memset of x inside (both legs alike)"}
 
 
+def one_problem_leg(ctx, NLO, cpu_seconds):
+    """The reference's typical call -- ONE problem (LBFGS takes one x: NO.f90:398-625) -- at n = 2^20: the fused solve shares the
+    problem among `groups` workgroups (csrc/fl_big.hpp, the cooperative form: one launch, a trial at many CUs' bandwidth plus a
+    barrier) against one workgroup (FL_COOP_GROUPS=1: one CU).  Parity: the oracle in the kernel's order with `groups`, bit for bit."""
+    import numpy as np
+    torch = ctx.torch
+    n, m = 1 << 20, 10
+    d, b = _quad(ctx, NLO, 1, n, 10.0, 100.0)
+    # (Precision 1e-4: |grad f|^2 < 1e-8 from 3.5e5 at x = 0.  1e-6 would ask for 1e-12 -- below the rounding noise of sums of
+    # 2^20 terms around f = -4e4, where it is luck which summation order gets through the last line searches: DESIGN.md 4.5c)
+    kw = dict(Precision=1e-4, MaxIteration=60, Memory=m)
+    ws = NLO.workspace(1, n, m, ctx.dev)
+    x = torch.zeros(1, n, dtype=torch.float64, device=ctx.dev)
+
+    def solve():
+        x.zero_()
+        return NLO.LBFGS(NLO.DIAGQUAD, x, d, b, workspace_=ws, **kw)
+    keep = os.environ.get("FL_COOP_GROUPS")
+    try:
+        os.environ.pop("FL_COOP_GROUPS", None)
+        G = NLO.cooperative_groups(NLO.LBFGS_, NLO.DIAGQUAD, 1, n)
+        out, ms = timed_launches(ctx, solve, 3)
+        xg = x.cpu().numpy().copy()
+        os.environ["FL_COOP_GROUPS"] = "1"
+        out1, ms1 = timed_launches(ctx, solve, 1)
+    finally:
+        if keep is None:
+            os.environ.pop("FL_COOP_GROUPS", None)
+        else:
+            os.environ["FL_COOP_GROUPS"] = keep
+    nf, it = int(out["nf"][0]), int(out["iters"][0])
+    # bytes one evaluation moves (x0, p read; x, g written; d, b read) and one two-loop recursion (2m pairs read twice, p written)
+    traffic = nf * 6 * n * 8 + it * (4 * m + 2) * n * 8
+    r = {"workload": f"ONE problem, L-BFGS m={m}, diagonal quadratic n=2^20 (kappa in [10,100]), Precision 1e-4, at most 60 iterations",
+         "workgroups_per_problem": G, "ms": ms, "ms_one_workgroup": ms1, "speedup": ms1 / ms, "iterations": it, "objective_evaluations": nf,
+         "status": int(out["status"][0]), "vector_traffic_GBps": traffic / ms / 1e6,
+         "us_per_reduction_step": ms * 1e3 / max(nf + it * (2 * m + 2), 1),
+         "note": "the sums' order -- and the last bits of x -- depend on workgroups_per_problem (fl_cooperative_groups_for reports it)"}
+    if cpu_seconds > 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        T, E = NLO.reduction_geometry(n, NLO.LBFGS_)
+        oo = O.defaults(precision=1e-4, maxit=60)
+        oo.memory = m
+        O.lib().flo_set_sum_groups(G)
+        t = time.perf_counter()
+        try:
+            o = O.solve_batch(O.LBFGS, O.DIAGQUAD, np.zeros((1, n)), d=d.cpu().numpy(), b=b.cpu().numpy(), opts=oo, sum_mode=O.TREE, threads=T,
+                              ept=E, nthreads=1)
+        finally:
+            O.lib().flo_set_sum_groups(1)
+        r["cpu_oracle_seconds_one_core"] = time.perf_counter() - t
+        r["parity"] = {"bit_identical_x": bool(np.array_equal(xg.view(np.uint64), o["x"].view(np.uint64))),
+                       "objective_evaluations": bool(int(o["nf"][0]) == nf), "iterations": bool(int(o["iters"][0]) == it)}
+        r["parity"]["ok"] = all(r["parity"].values())
+    return r
+
+
 CONFIGS = {"c2": config_c2, "c3": config_c3, "c4": config_c4, "c4gemm": config_c4gemm, "c5": config_c5}
 MULTI_GPU_CONFIGS = ("c3", "c5")  # BASELINE.json: "sharded 1/2/4/8 GPUs", "8xMI355X"
 
@@ -1058,6 +1116,7 @@ def main():
 
     if names and ctx.world == 1 and ctx.rank == 0:
         res["user_objective_compiled_at_run_time"] = rtc_leg(ctx, NLO)
+        res["one_problem_of_a_million_unknowns"] = one_problem_leg(ctx, NLO, args.config_cpu_seconds)
 
     bad = False
     if ctx.rank == 0:
