@@ -961,7 +961,7 @@ def one_problem_leg(ctx, NLO, cpu_seconds):
     n, m = 1 << 20, 10
     d, b = _quad(ctx, NLO, 1, n, 10.0, 100.0)
     # (Precision 1e-4: |grad f|^2 < 1e-8 from 3.5e5 at x = 0.  1e-6 would ask for 1e-12 -- below the rounding noise of sums of
-    # 2^20 terms around f = -4e4, where it is luck which summation order gets through the last line searches: DESIGN.md 4.5c)
+    # 2^20 terms around f = -4e4, where it is luck which summation order gets through the last line searches: DESIGN.md 4.5b)
     kw = dict(Precision=1e-4, MaxIteration=60, Memory=m)
     ws = NLO.workspace(1, n, m, ctx.dev)
     x = torch.zeros(1, n, dtype=torch.float64, device=ctx.dev)

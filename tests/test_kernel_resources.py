@@ -73,8 +73,9 @@ def test_scalar_spills_of_the_baseline_kernels_stay_where_they_are(kernels):
     has ~60 uniform doubles (line search 19, solver 12, augmented Lagrangian 4, ...) plus the kernel's argument block, against 102
     SGPRs; the allocator keeps the hot loops' scalars in SGPRs and parks the rest in lanes.  Caps = the achieved numbers plus the
     allocator's jitter: headline (L-BFGS 2x8), C2 (1x4 Rosenbrock), C3 (CG 1x16), C4 (BFGS 8x8), C5 (aug-Lagrangian 1x8)."""
-    caps = {"fl_solve_kernel<2, 8, 2, 2, 0, 0>": 40, "fl_solve_kernel<1, 4, 1, 2, 0, 0>": 40, "fl_solve_kernel<1, 16, 2, 1, 0, 0>": 20,
-            "fl_solve_kernel<8, 8, 2, 3, 0, 0>": 280, "fl_solve_kernel<1, 8, 2, 2, 1, 0>": 640}
+    # (achieved at the round's end: 29, 21, 0, 224, 572)
+    caps = {"fl_solve_kernel<2, 8, 2, 2, 0, 0>": 32, "fl_solve_kernel<1, 4, 1, 2, 0, 0>": 24, "fl_solve_kernel<1, 16, 2, 1, 0, 0>": 0,
+            "fl_solve_kernel<8, 8, 2, 3, 0, 0>": 230, "fl_solve_kernel<1, 8, 2, 2, 1, 0>": 590}
     # (round 4: C4 302 -> 200-250; C5's count moves by +-50 with any edit of the machine -- 515 ... 588 -- while its hot loop, the
     #  objective-only shrink loop, holds 37 lane moves per 689 instructions: DESIGN.md 4.1)
     seen = 0
@@ -88,7 +89,8 @@ def test_scalar_spills_of_the_baseline_kernels_stay_where_they_are(kernels):
 
 def test_cooperative_barrier_waits_for_its_partial_sums_before_it_counts_the_arrival():
     """csrc/fl_big.hpp coop_barrier: thread 0's write-through stores of the partial sums must have left the
-    wave before the arrival is counted -- in the ISA of every rci_step_big_kernel an `s_waitcnt vmcnt(0)` stands between the
+    wave before the arrival is counted -- in the ISA of every rci_step_big_kernel (and, since round 4, fl_big_solve_kernel) an
+    `s_waitcnt vmcnt(0)` stands between the
     workgroup barrier and the `global_atomic_add` of the arrival (round 3 had the stores, s_barrier and the add with no wait)."""
     import re
     import subprocess
@@ -97,7 +99,7 @@ def test_cooperative_barrier_waits_for_its_partial_sums_before_it_counts_the_arr
         pytest.skip("libFL.so not built")
     seen = 0
     for img in KR.code_objects(LIB):
-        if b"rci_step_big_kernel" not in img:
+        if b"rci_step_big_kernel" not in img and b"fl_big_solve_kernel" not in img:
             continue
         with tempfile.NamedTemporaryFile(suffix=".co") as fh:
             fh.write(img)
@@ -109,7 +111,7 @@ def test_cooperative_barrier_waits_for_its_partial_sums_before_it_counts_the_arr
             if m:
                 cur, window = m.group(1), []
                 continue
-            if cur is None or "rci_step_big_kernel" not in cur:
+            if cur is None or ("rci_step_big_kernel" not in cur and "fl_big_solve_kernel" not in cur):
                 continue
             ins = line.split("//")[0].strip()
             if not ins:
@@ -120,4 +122,4 @@ def test_cooperative_barrier_waits_for_its_partial_sums_before_it_counts_the_arr
             if ins.startswith("global_atomic_add"):
                 seen += 1
                 assert any(re.match(r"s_waitcnt\s+vmcnt\(0\)", w) for w in window), (cur, window[-12:])
-    assert seen >= 4, "one arrival atomic per solver instance of the cooperative step kernel"
+    assert seen >= 4 + 6, "one arrival atomic per solver instance of the cooperative step kernel and of the fused kernels (SD / CG / L-BFGS x 2 objectives)"
