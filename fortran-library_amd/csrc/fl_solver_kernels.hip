@@ -22,6 +22,8 @@
 namespace fl {
 
 static int device_compute_units();
+// problems other host threads of this process run on the same device at the same time (fl_multi_solve's shards): 0 = none known
+static thread_local int tls_concurrent_batch = 0;
 
 // n > 4096: vectors in HBM, one workgroup of 1024 threads per problem (fl_big.hpp: fl_big_solve_kernel) -- or, for few
 // problems, `groups` workgroups per problem (the cooperative form)
@@ -70,6 +72,9 @@ int big_cooperative_groups(int method, int objective, int batch, int n, bool coo
     if (cus > BS::COOP_MAX_GROUPS) cus = BS::COOP_MAX_GROUPS;
     if (per_cu < 1) return 1;
     const int nslot = BS::slots_for(n);
+    // (fl_multi_solve runs several shards per device at once: all their workgroups must be resident TOGETHER, or the barriers of
+    // one shard would spin for CUs the others hold)
+    if (tls_concurrent_batch > batch) batch = tls_concurrent_batch;
     int want = cus / batch;
     if (want > nslot / 2) want = nslot / 2;
     // (beyond 64 the barrier outweighs the bandwidth: thread 0's poll, G partial sums to fetch and add left to right per
@@ -189,7 +194,6 @@ static int device_compute_units()
 #define FL_STAGE_T4 512  // ... and the three-helper stage
 #endif
 // (fl_multi_solve runs several shards on one device at once: each of its threads says how many problems the device holds)
-static thread_local int tls_concurrent_batch = 0;
 static int select_replicas(const GeoSel &g, int objective, int method, int n, int m, int batch)
 {
     if (tls_concurrent_batch > batch) batch = tls_concurrent_batch;

@@ -125,7 +125,9 @@ int fl_reduction_geometry_for(int solver, int n, int *threads, int *ept);
  * workgroup owns a contiguous range of every thread's elements; every sum is then: the workgroups' sums in the usual order,
  * added left to right -- so the last bits of a result depend on `groups`, which this call reports for a batch on the
  * current device (1: none).  FL_COOP_GROUPS=<g> in the environment overrides the choice (1: never).  A problem whose
- * workgroups could not all be resident ends with FL_STATUS_NOT_SOLVED (the device was shared with other work). */
+ * workgroups could not all be resident ends with FL_STATUS_NOT_SOLVED (the device was shared with other work: calls that run side
+ * by side on one device from several streams or threads of YOURS should set FL_COOP_GROUPS=1; fl_multi_solve's own shards
+ * size their groups for the device's whole load). */
 int fl_cooperative_groups_for(int solver, int objective, int batch, int n);
 
 /* The fused L-BFGS kernel keeps the newest pairs of its (s, y) ring on the chip (registers, then an LDS ring); this

@@ -150,3 +150,23 @@ def test_one_problem_of_a_million_unknowns_fills_the_chip(monkeypatch, capsys):
     assert res["coop"][3] >= 0 and res["one"][3] >= 0
     assert np.abs(res["coop"][0] - res["one"][0]).max() < 1e-5
     assert ms["coop"] * 5 < ms["one"]
+
+
+def test_shards_running_side_by_side_on_one_device_size_their_groups_for_the_devices_load(monkeypatch):
+    """fl_multi_solve runs up to four shards per device at once: every shard's cooperative launch must leave room for the others'
+    workgroups (their barriers spin) -- the groups are chosen from the device's load, not the shard's, which also makes the
+    sharded result the one-call result bit for bit"""
+    NLO = _nlo()
+    dev = torch.device("cuda:0")
+    monkeypatch.delenv("FL_COOP_GROUPS", raising=False)
+    B, n = 4, 30001
+    d, b = _quads(B, n, 11)
+    assert NLO.cooperative_groups(NLO.LBFGS_, O.DIAGQUAD, B, n) > 1
+    xh = np.zeros((B, n))
+    om = NLO.multi_solve(NLO.LBFGS_, NLO.DIAGQUAD, xh, d, b, nshards=4, Precision=1e-6, MaxIteration=100)
+    assert np.all(om["status"] >= 0), om["status"]
+    x = torch.zeros(B, n, dtype=torch.float64, device=dev)
+    o1 = NLO.LBFGS(NLO.DIAGQUAD, x, torch.tensor(d, device=dev), torch.tensor(b, device=dev), Precision=1e-6, MaxIteration=100)
+    torch.cuda.synchronize()
+    assert np.array_equal(xh.view(np.uint64), x.cpu().numpy().view(np.uint64))
+    assert np.array_equal(om["nf"], o1["nf"].cpu().numpy())
