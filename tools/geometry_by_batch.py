@@ -90,6 +90,19 @@ def workload(name, B):
             x.copy_(x0)
             return NLO.LBFGS(NLO.ROSENBROCK, x, workspace_=ws, Precision=1e-10, MaxIteration=3000, Memory=m)
         return run, ["1x4"]
+    if name == "c4":  # dense BFGS n = 4096, a fixed 20 iterations (bench.py config_c4)
+        n = 4096
+        d, b = quad(B, n, 10.0, 100.0)
+        x = torch.zeros(B, n, dtype=torch.float64, device=dev)
+        opt = NLO.default_options(NLO.BFGS_, Precision=1e-12, MaxIteration=19, ExactStep=0)
+        import ctypes as C
+        nbytes = NLO.FL.fl_workspace_bytes_for(NLO.BFGS_, B, n, C.byref(opt))
+        ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=dev)
+
+        def run():
+            x.zero_()
+            return NLO.BFGS(NLO.DIAGQUAD, x, d, b, workspace_=ws, Precision=1e-12, MaxIteration=19, ExactStep=0)
+        return run, ["8x8"]
     raise SystemExit("unknown workload " + name)
 
 

@@ -32,6 +32,6 @@ for geo in a.geos.split(","):
     k = int(tot.argmax())
     row = {"geometry": geo, "kernel_ms": round(e0.elapsed_time(e1), 2), "slowest_problem": k,
            "slowest": {n: [round(t[k, i] * 1e-5, 2), int(t[k, 6 + i])] for i, n in enumerate(names)},
-           "slowest_total_ms": round(tot[k] * 1e-5, 2), "slowest_nf_ng_iters_outer": [int(out[q][k]) for q in ("nf", "ng", "iters", "outer")],
+           "slowest_total_ms": round(tot[k] * 1e-5, 2), "slowest_nf_ng_iters_outer": [int(out[q][k]) for q in ("nf", "ng", "iters", "outer") if q in out],
            "mean": {n: [round(t[:, i].mean() * 1e-5, 2), int(t[:, 6 + i].mean())] for i, n in enumerate(names)}}
     print(json.dumps(row), flush=True)
