@@ -469,7 +469,8 @@ def auglag_hessian(fdd, cdd, cd, c, lam, miu):
 def minimize_rci_auglag(solver, x, fun, M, lambda0=None, miu0=1.0, options=None, max_steps=10000000, check_every=8, hess=None, **kw):
     """AugmentedLagrangian (NO.f90:2005) for a batch with the caller's objective AND equality constraints, by reverse
     communication: `fun(x)` returns (f[batch], g[batch, n], c[batch, M], cd[batch, M, n]) CUDA tensors for the whole
-    batch (cd[k, j] = grad c_j at x_k).  solver (the inner one): LBFGS_ | CG | BFGS_ | 4 (NewtonRaphson).  NewtonRaphson, and
+    batch (cd[k, j] = grad c_j at x_k).  solver (the inner one): LBFGS_ | CG | BFGS_ | 4 (NewtonRaphson); any n for the first three
+    (BFGS_ to 16384), n <= 4096 with Hessians.  NewtonRaphson, and
     BFGS_ with ExactStep > 0, take the Hessian of L (the reference's fdd / cdd branch, NO.f90:2074-2148): pass
     hess=callable `hess(x) -> (fdd[batch, n, n], cdd[batch, M, n, n] | None)` -- Ldd is assembled from them as the reference
     does (auglag_hessian) -- or hess="numerical": central differences of grad L with djacobi's step rule, like the reference

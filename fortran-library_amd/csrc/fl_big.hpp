@@ -46,7 +46,10 @@ struct BigUserObjective { // (placeholder: BigSolver<FL_OBJ_USER, .> is instanti
 #endif
 struct BigNoObjective {};
 
-template <int OBJ, int METHOD> struct BigSolver {
+// AUG = 1 (reverse communication only, OBJ = FL_OBJ_EXTERNAL): the AugmentedLagrangian outer loop (NO.f90:2150-2185) around the
+// solver with the CALLER's f, f', c, c' -- Solver<..., AUG>::take_external_aug and inner_finished restated over vectors in HBM.
+template <int OBJ, int METHOD, int AUG = 0> struct BigSolver {
+    static_assert(!AUG || OBJ == FL_OBJ_EXTERNAL, "beyond n = 4096 the augmented Lagrangian runs by reverse communication");
     static_assert(METHOD == FL_SOLVER_SD || METHOD == FL_SOLVER_CG || METHOD == FL_SOLVER_LBFGS ||
                       METHOD == FL_SOLVER_BFGS,
                   "vectors-in-HBM path: SD, CG, L-BFGS, BFGS (quasi-Newton updates only)");
@@ -66,7 +69,9 @@ template <int OBJ, int METHOD> struct BigSolver {
     // cooperative form (reverse communication only): the partial sums of up to COOP_MAX_GROUPS workgroups, staged for the
     // left-to-right addition
     static constexpr int COOP_MAX_GROUPS = 256;
-    static constexpr int LDS_TOTAL = L_COOP + (METHOD != FL_SOLVER_BFGS ? COOP_MAX_GROUPS * Reducer<16>::NVMAX : 0);
+    static constexpr int L_LAM = L_COOP + (METHOD != FL_SOLVER_BFGS ? COOP_MAX_GROUPS * Reducer<16>::NVMAX : 0); // lambda[FL_MAX_CONSTRAINTS]
+    static constexpr int L_CX = L_LAM + (AUG ? FL_MAX_CONSTRAINTS : 0);                                           // c(x)[FL_MAX_CONSTRAINTS]
+    static constexpr int LDS_TOTAL = L_CX + (AUG ? FL_MAX_CONSTRAINTS : 0);
     // the cooperative form needs every element touched by its owner alone: not BFGS (the dense H is folded across rows), not an
     // objective that reads its neighbours' x (written by another workgroup, possibly behind another XCD's L2)
     static constexpr bool COOP_OK = METHOD != FL_SOLVER_BFGS && !(OBJ == FL_OBJ_ROSENBROCK || (OBJ == FL_OBJ_USER && BigUserObjective::NEIGHBOURS));
@@ -88,6 +93,8 @@ template <int OBJ, int METHOD> struct BigSolver {
     int recent, cnt;
     double yy_recent, rho_recent;
     int main_it, h_valid, ndef, h_ident; // BFGS (names as in Solver)
+    double miu, cc;                      // augmented Lagrangian (names as in Solver)
+    int outer_it, inner_iters_total;
     double a_id;
     LineSearch ls;
     typename pick_type<OBJ == FL_OBJ_USER, BigUserObjective, BigNoObjective>::type uo; // the caller's streaming functor
@@ -279,7 +286,14 @@ template <int OBJ, int METHOD> struct BigSolver {
         a_id = 0.0;
         phase = PH_INIT;
         pending = 0;
+        miu = cc = 0.0;
+        outer_it = inner_iters_total = 0;
         if constexpr (OBJ == FL_OBJ_USER) uo.init(A, prob);
+        if constexpr (AUG) { // (lambda lives in LDS during a launch and in the caller's array between launches)
+            miu = A.miu0 > 1.0 ? A.miu0 : 1.0; // miu=max(1d0,miu0)
+            if (tid < A.aug_m) lds[L_LAM + tid] = A.lambda[(size_t)prob * A.aug_m + tid];
+            __syncthreads();
+        }
     }
     // the caller's terms for one element pair, padding forced to zero
     __device__ __forceinline__ void user_pair(int e, double xa, double xb, double &ta, double &tb, double &ua, double &ub, double &ga, double &gb)
@@ -478,6 +492,51 @@ template <int OBJ, int METHOD> struct BigSolver {
         ggo = uni(r[1]);
     }
 
+    // reverse communication, augmented Lagrangian: the caller's f, grad f [n], c [m], cd [m][n] -> L = f - lambda.c + miu/2 c.c and
+    // grad L = grad f + cd^T (miu c - lambda), the sum over the constraints in order (L, Ld: NO.f90:2193-2228;
+    // Solver::take_external_aug), with grad L . p and |grad L|^2
+    __device__ __forceinline__ void take_external_aug(double fuser, bool have_f, bool have_g, const double *g_user, const double *c_user,
+                                                      const double *cd_user, double &f, double &gp, double &ggo)
+    {
+        const int m = A.aug_m;
+        double *cxs = lds + L_CX;
+        __syncthreads(); // readers of the previous c(x) are done
+        if (tid < m) cxs[tid] = c_user[tid];
+        __syncthreads();
+        if (have_f) {
+            double lc = 0.0, c2 = 0.0;
+            for (int j = 0; j < m; ++j) {
+                lc = lc + lds[L_LAM + j] * cxs[j];
+                c2 = c2 + cxs[j] * cxs[j];
+            }
+            f = uni(fuser - lc + miu / 2.0 * c2);
+        }
+        if (have_g) {
+            double r[2] = {0.0, 0.0};
+            for (int c = c_lo; c < c_hi; ++c) {
+                const int e = e_of(c);
+                double ga, gb, pa, pb, ta = 0.0, tb = 0.0;
+                ldu(g_user, e, ga, gb);
+                for (int j = 0; j < m; ++j) {
+                    const double v = miu * cxs[j] - lds[L_LAM + j];
+                    double ra, rb;
+                    ldu(cd_user + (size_t)j * n, e, ra, rb);
+                    ta = ta + ra * v;
+                    tb = tb + rb * v;
+                }
+                ga = ga + ta;
+                gb = gb + tb;
+                stw(g, e, ga, gb);
+                ldw(p, e, pa, pb);
+                acc2(r[0], c, ga * pa, gb * pb);
+                acc2(r[1], c, ga * ga, gb * gb);
+            }
+            reduce(r);
+            gp = uni(r[0]);
+            ggo = uni(r[1]);
+        }
+    }
+
     // ---------------------------------------------------------------- machine (Solver::advance and friends)
     // (an objective that is not a number ends the problem: see Solver::not_finite)
     __device__ __forceinline__ bool not_finite(double fv) const { return (pending & FL_REQ_F) && fv != fv; }
@@ -516,8 +575,40 @@ template <int OBJ, int METHOD> struct BigSolver {
         if constexpr (METHOD == FL_SOLVER_BFGS) return 0x7fffffff; // counted by main_it in begin_linesearch
         return A.maxit;
     }
-    __device__ __forceinline__ int finished()
+    __device__ __forceinline__ int finished() // (the inner solve is over: Solver::inner_finished)
     {
+        if constexpr (AUG) {
+            const int m = A.aug_m;
+            const double *cxs = lds + L_CX; // c(x) of the last evaluation = c at the current x
+            double c2 = 0.0;
+            for (int j = 0; j < m; ++j) c2 = c2 + cxs[j] * cxs[j];
+            cc = uni(c2);
+            ++outer_it;
+            inner_iters_total += iters;
+            iters = 0;
+            if (c2 < A.precision * A.precision) { // if(dot_product(cx,cx)<tolsq) exit
+                status = FL_STATUS_CONVERGED;
+                phase = PH_DONE;
+                return 0;
+            }
+            __syncthreads();
+            if (tid < m) lds[L_LAM + tid] = lds[L_LAM + tid] - miu * cxs[tid]; // lambda=lambda-miu*cx
+            __syncthreads();
+            miu = uni(miu * A.incr); // miu=miu*incrmt
+            if (outer_it >= A.maxit) {
+                status = FL_STATUS_MAXIT;
+                phase = PH_DONE;
+                return 0;
+            }
+            recent = -1; // a fresh inner solve from the current x: it starts with an evaluation of L, L'
+            cnt = 0;
+            main_it = 0;
+            h_valid = 0;
+            ndef = 0;
+            h_ident = 0;
+            phase = PH_INIT;
+            return FL_REQ_F | FL_REQ_G | FL_REQ_NOMOVE;
+        }
         phase = PH_DONE;
         return 0;
     }
@@ -533,6 +624,7 @@ template <int OBJ, int METHOD> struct BigSolver {
     __device__ __forceinline__ int begin_linesearch()
     {
         int fused = A.fused;
+        if constexpr (AUG) fused = 1; // AugmentedLagrangian always passes f_fd=L_Ld (NO.f90:2153, 2161)
         if constexpr (METHOD == FL_SOLVER_LBFGS) fused = fused && (iters >= A.mem); // NO.f90:448-460, 486-498
         if constexpr (METHOD == FL_SOLVER_BFGS) { // main loop do iIteration=1,maxit (NO.f90:717-929); the first step precedes it
             if (h_valid) {
@@ -997,6 +1089,17 @@ template <int OBJ, int METHOD> struct BigSolver {
             *iq++ = recent; *iq++ = cnt; *iq++ = ls.st; *iq++ = ls.zret; *iq++ = ls.fused;
             *iq++ = main_it; *iq++ = h_valid; *iq++ = ndef; *iq++ = h_ident;
             sc[29] = a_id;
+            if constexpr (AUG) { // the outer loop (the multipliers themselves: A.lambda, below)
+                sc[40] = miu;
+                sc[41] = cc;
+                int *aq = reinterpret_cast<int *>(sc + 42);
+                aq[0] = outer_it;
+                aq[1] = inner_iters_total;
+            }
+        }
+        if constexpr (AUG) {
+            __syncthreads();
+            if (tid < A.aug_m) A.lambda[(size_t)prob * A.aug_m + tid] = lds[L_LAM + tid];
         }
     }
     __device__ __forceinline__ void load(const double *sc, const double *rho, double &fv_c, double &pv_c)
@@ -1017,6 +1120,13 @@ template <int OBJ, int METHOD> struct BigSolver {
         recent = *iq++; cnt = *iq++; ls.st = *iq++; ls.zret = *iq++; ls.fused = *iq++;
         main_it = *iq++; h_valid = *iq++; ndef = *iq++; h_ident = *iq++;
         a_id = sc[29];
+        if constexpr (AUG) {
+            miu = uni(sc[40]);
+            cc = uni(sc[41]);
+            const int *aq = reinterpret_cast<const int *>(sc + 42);
+            outer_it = __builtin_amdgcn_readfirstlane(aq[0]);
+            inner_iters_total = __builtin_amdgcn_readfirstlane(aq[1]);
+        }
         pin_scalars();
         // every wave has read the parked scalars before thread 0 may overwrite them in save(): a step that only
         // takes an objective value has no other barrier (cooperative form: every workgroup of the problem has)
@@ -1049,10 +1159,14 @@ template <int OBJ, int METHOD> struct BigSolver {
             if (G > 1 && __hip_atomic_load(coop_counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) status = FL_STATUS_NOT_SOLVED;
             if (A.f_out) A.f_out[prob] = fnew;
             if (A.gg_out) A.gg_out[prob] = gg;
-            if (A.iters) A.iters[prob] = iters;
+            if (A.iters) A.iters[prob] = iters + inner_iters_total;
             if (A.status) A.status[prob] = status;
             if (A.nf) A.nf[prob] = nf;
             if (A.ng) A.ng[prob] = ng;
+            if constexpr (AUG) {
+                if (A.outer) A.outer[prob] = outer_it;
+                if (A.cnorm2) A.cnorm2[prob] = cc;
+            }
         }
     }
 };

@@ -119,13 +119,16 @@ __global__ __launch_bounds__(NW * 64) void rci_step_kernel(SolveArgs A, int firs
 // groups > 1: the COOPERATIVE form -- `groups` workgroups share one problem (BigSolver::set_cooperative): blockIdx.x =
 // problem * groups + group.  For few problems of very large n (the reference's callers typically solve ONE problem of
 // any dim): a single n = 2^20 problem then occupies the whole chip instead of one CU.
-template <int METHOD>
+// AUG = 1: the augmented Lagrangian around the solver with the caller's c [batch][m] and cd [batch][m][n] (round 4: until then the
+// constrained form stopped at n = 4096; one workgroup per problem -- lambda has one copy, so no cooperative form)
+template <int METHOD, int AUG = 0>
 __global__ __launch_bounds__(1024) void rci_step_big_kernel(SolveArgs A, int first, double *sc_all, double *vec_all,
                                                             double *rho_all, const double *f_dev, const double *g_dev,
                                                             int32_t *request, int groups, double *coop_part,
-                                                            unsigned *coop_counter, int parity, unsigned *coop_host_flag)
+                                                            unsigned *coop_counter, int parity, unsigned *coop_host_flag,
+                                                            const double *c_dev = nullptr, const double *cd_dev = nullptr)
 {
-    using S = BigSolver<FL_OBJ_EXTERNAL, METHOD>;
+    using S = BigSolver<FL_OBJ_EXTERNAL, METHOD, AUG>;
     __shared__ __attribute__((aligned(16))) double lds[S::LDS_TOTAL];
     const int prob = blockIdx.x / groups, group = blockIdx.x - prob * groups, n = A.n;
     S s(A, lds, vec_all, prob);
@@ -151,14 +154,24 @@ __global__ __launch_bounds__(1024) void rci_step_big_kernel(SolveArgs A, int fir
             return;
         }
         double ggv = s.gg;
-        if ((s.pending & FL_REQ_F) && f_dev) fv = f_dev[prob];
-        if ((s.pending & FL_REQ_G) && g_dev) s.take_gradient(g_dev + (size_t)prob * n, pv, ggv);
+        if constexpr (AUG) {
+            const bool have_f = (s.pending & FL_REQ_F) && f_dev, have_g = (s.pending & FL_REQ_G) && g_dev;
+            s.take_external_aug(have_f ? f_dev[prob] : 0.0, have_f, have_g, g_dev + (size_t)prob * n, c_dev + (size_t)prob * A.aug_m,
+                                cd_dev + (size_t)prob * A.aug_m * n, fv, pv, ggv);
+        } else {
+            if ((s.pending & FL_REQ_F) && f_dev) fv = f_dev[prob];
+            if ((s.pending & FL_REQ_G) && g_dev) s.take_gradient(g_dev + (size_t)prob * n, pv, ggv);
+        }
         rq = s.advance(fv, pv, ggv);
     }
     if (rq == 0) s.finish();
     else if (!(rq & (FL_REQ_SAME | FL_REQ_NOMOVE))) s.move(s.request_point());
     s.save(sc, rho, fv, pv);
-    if (threadIdx.x == 0 && group == 0) request[prob] = rq;
+    if (threadIdx.x == 0 && group == 0) {
+        int out = rq;
+        if (AUG && rq != 0) out |= FL_REQ_C | ((rq & FL_REQ_G) ? FL_REQ_CD : 0);
+        request[prob] = out;
+    }
 }
 
 // ------------------------------------------------------------------ the line searchers on their own
@@ -324,7 +337,7 @@ static void launch_rci(Rci *h, const double *f, const double *g, const double *c
 #undef FL_RCI_AUG
 }
 
-static void launch_rci_big(Rci *h, const double *f, const double *g, int32_t *req)
+static void launch_rci_big(Rci *h, const double *f, const double *g, int32_t *req, const double *c = nullptr, const double *cd = nullptr)
 {
     const int G = h->coop_groups > 1 ? h->coop_groups : 1;
     if (G > 1) // this launch's barriers count from 0 (word 0 of each problem's pair; word 1 is the "gave up waiting" flag: kept)
@@ -333,6 +346,17 @@ static void launch_rci_big(Rci *h, const double *f, const double *g, int32_t *re
 #define FL_RCI(M)                                                                                                 \
     hipLaunchKernelGGL((rci_step_big_kernel<M>), grid, block, 0, h->stream, h->A, h->first, h->sc, h->vec, h->rho, f, \
                        g, req, G, h->coop_part, h->coop_counter, h->parity, h->coop_flag_dev)
+#define FL_RCI_AUG(M)                                                                                                  \
+    hipLaunchKernelGGL((rci_step_big_kernel<M, 1>), grid, block, 0, h->stream, h->A, h->first, h->sc, h->vec, h->rho, f, \
+                       g, req, 1, h->coop_part, h->coop_counter, h->parity, h->coop_flag_dev, c, cd)
+    if (h->aug) { // AugmentedLagrangian around L-BFGS, ConjugateGradient or quasi-Newton BFGS (NO.f90:2131-2185)
+        switch (h->solver) {
+        case FL_SOLVER_CG: FL_RCI_AUG(FL_SOLVER_CG); break;
+        case FL_SOLVER_BFGS: FL_RCI_AUG(FL_SOLVER_BFGS); break;
+        default: FL_RCI_AUG(FL_SOLVER_LBFGS); break;
+        }
+        return;
+    }
     switch (h->solver) {
     case FL_SOLVER_SD: FL_RCI(FL_SOLVER_SD); break;
     case FL_SOLVER_CG: FL_RCI(FL_SOLVER_CG); break;
@@ -340,6 +364,7 @@ static void launch_rci_big(Rci *h, const double *f, const double *g, int32_t *re
     default: FL_RCI(FL_SOLVER_LBFGS); break;
     }
 #undef FL_RCI
+#undef FL_RCI_AUG
     if (G > 1) h->parity ^= 1;
 }
 
@@ -506,7 +531,7 @@ static int rci_step_any(fl_rci *h, double *x_dev, const double *f_dev, const dou
         if (active_dev || flags) return FL_ERR_UNSUPPORTED_SIZE; // (the vectors-in-HBM path steps whole batches)
         // a cooperative barrier of an earlier step gave up (its siblings were not resident): nothing since can be trusted
         if (r->coop_flag_host && *(volatile unsigned *)r->coop_flag_host != 0u) return FL_ERR_LAUNCH;
-        fl::launch_rci_big(r, f_dev, g_dev, request_dev);
+        fl::launch_rci_big(r, f_dev, g_dev, request_dev, c_dev, cd_dev);
     }
     else if (nw == 1 && ept == 2) fl::launch_rci<1, 2>(r, f_dev, g_dev, c_dev, cd_dev, request_dev, flags, active_dev, nactive, xio);
     else if (nw == 1 && ept == 4) fl::launch_rci<1, 4>(r, f_dev, g_dev, c_dev, cd_dev, request_dev, flags, active_dev, nactive, xio);
@@ -556,11 +581,13 @@ int fl_rci_create_auglag(fl_rci **out, int solver, int batch, int n, int m, doub
     if (solver != FL_SOLVER_LBFGS && solver != FL_SOLVER_CG && solver != FL_SOLVER_BFGS && solver != FL_SOLVER_NEWTON)
         return FL_ERR_INVALID_ARGUMENT;
     if (!opt || m < 1 || m > FL_MAX_CONSTRAINTS || !lambda_dev) return FL_ERR_INVALID_ARGUMENT;
-    if (n > 4096) return FL_ERR_UNSUPPORTED_SIZE; // like fl_augmented_lagrangian_batched: the register path only
-    // NewtonRaphson, and BFGS with exact_step > 0, ask for the Hessian of L (FL_REQ_H: NO.f90:2229-2241, Ldd)
+    // NewtonRaphson, and BFGS with exact_step > 0, ask for the Hessian of L (FL_REQ_H: NO.f90:2229-2241, Ldd): the register path
+    // only (n <= 4096).  L-BFGS, CG and quasi-Newton BFGS go on beyond it with the vectors in HBM (round 4; BFGS to n = 16384)
+    if (n > 4096 && (solver == FL_SOLVER_NEWTON || (solver == FL_SOLVER_BFGS && opt->exact_step > 0))) return FL_ERR_UNSUPPORTED_SIZE;
     const int rc = fl_rci_create(out, solver, batch, n, opt, stream);
     if (rc != FL_OK) return rc;
     fl::Rci &r = (*out)->r;
+    r.coop_groups = 1; // (one copy of lambda per problem: one workgroup per problem)
     const size_t B = (size_t)batch;
     if (hipMalloc((void **)&r.outer, B * sizeof(int32_t)) != hipSuccess ||
         hipMalloc((void **)&r.cnorm2, B * sizeof(double)) != hipSuccess) {

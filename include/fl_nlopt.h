@@ -430,7 +430,8 @@ int fl_rci_destroy(fl_rci *handle);
  * inside the step kernel.  Requests carry two more bits: FL_RCI_REQ_C (32) -- with EVERY request: c_dev[batch][m] =
  * c(x) at the requested point -- and FL_RCI_REQ_CD (64) -- with every gradient request: cd_dev[batch][m][n], row j =
  * grad c_j(x) (the Fortran array cdx(N,M) as it lies in memory).  L = f - lambda.c + miu/2 c.c and
- * grad L = grad f + cd^T (miu c - lambda) (NO.f90:2198, 2205) are formed in the kernel; m <= 16, n <= 4096.
+ * grad L = grad f + cd^T (miu c - lambda) (NO.f90:2198, 2205) are formed in the kernel; m <= 16.  Any n: beyond 4096 the
+ * machine's vectors live in HBM (1024 threads per problem, fl_reduction_geometry; FL_SOLVER_BFGS to n = 16384), whole-batch steps.
  * lambda_dev [batch][m]: lambda0 on entry, the multipliers afterwards (updated in place from step to step; must stay
  * valid while the handle lives).  opt->precision is the inner gradient tolerance AND the outer ||c|| tolerance,
  * opt->max_iteration bounds both loops, opt->increment is the line-search growth factor AND the miu growth factor
@@ -441,7 +442,7 @@ int fl_rci_destroy(fl_rci *handle);
  * for the HESSIAN OF L (bit 4, FL_REQ_H = 16, at an unchanged point): the caller forms it as the reference's Ldd does
  * (NO.f90:2229-2241),  Ldd = f'' + sum_j c_j'' (miu c_j - lambda_j) + cd cd^T  -- lambda from lambda_dev, miu from
  * fl_rci_auglag_miu -- writes it with fl_rci_put_hessians (or into fl_rci_hessian_buffer) and steps again with the same f,
- * g, c, cd arrays; n <= 4096 like every aug-Lagrangian handle.  Without f'' / c'' the reference differentiates grad L by MKL's djacobi:
+ * g, c, cd arrays; n <= 4096 for these two (dense Cholesky: the register path).  Without f'' / c'' the reference differentiates grad L by MKL's djacobi:
  * fl_fd_points / fl_fd_column do that for a batch with djacobi's step rule (2n gradient evaluations per Hessian). */
 #define FL_RCI_REQ_C 32
 #define FL_RCI_REQ_CD 64
