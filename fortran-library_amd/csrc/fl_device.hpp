@@ -150,6 +150,33 @@ template <int NW, int EPT> __device__ __forceinline__ void load_pad(const double
         }
     }
 }
+// the same for a row that is read ONCE per pass and not again before the whole matrix has gone by (the dense inverse Hessian
+// of BFGS in its deferred form, n^2 doubles per problem against an L2 of 4 MB per XCD): NON-TEMPORAL accesses.  FL_BFGS_NT: 1 = the
+// loads of the product H (y, g), 2 = + the fold's loads, 3 = + the fold's stores.  BASELINE config 4 (1024 x n = 4096, 20
+// iterations; two rounds each): 0: 376.8 / 382.1 ms, 1: 358.0 / 361.8, 2: 356.8 / 361.2, 3: 355.7 / 356.3
+// (profiles/r04/c4_nontemporal_ab.txt; with it, three and four columns in flight stay behind two: 360 / 366 ms)
+#ifndef FL_BFGS_NT
+#define FL_BFGS_NT 3
+#endif
+template <int NW, int EPT> __device__ __forceinline__ void load_pad_nt(const double *row, double (&v)[EPT])
+{
+    using G = Geo<NW, EPT>;
+    typedef double fl_d2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int c = 0; c < G::NCH; ++c) {
+        const fl_d2 t = __builtin_nontemporal_load(reinterpret_cast<const fl_d2 *>(row + G::e0(c)));
+        v[2 * c] = t.x;
+        v[2 * c + 1] = t.y;
+    }
+}
+template <int NW, int EPT> __device__ __forceinline__ void load_pad_stream(const double *row, double (&v)[EPT])
+{
+#if FL_BFGS_NT
+    load_pad_nt<NW, EPT>(row, v);
+#else
+    load_pad<NW, EPT>(row, v);
+#endif
+}
 template <int NW, int EPT> __device__ __forceinline__ void store_pad(double *row, const double (&v)[EPT])
 {
     using G = Geo<NW, EPT>;
@@ -1960,6 +1987,9 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
             int s = recent - j;
             return s < 0 ? s + mem : s;
         };
+        // (the ring's rows are NOT streamed past the caches: non-temporal fetches take the headline from 155.3 ms to 181.6 on the
+        // way down only, 161.0 on the way up only, 235 on both -- what is read on the way down comes back from the Infinity Cache
+        // on the way up and in the next iteration; profiles/r04/c4_nontemporal_ab.txt)
         auto fetch = [&](int j, double (&s_)[EPT], double (&y_)[EPT]) { // j >= RP: the pairs behind the register pairs
             if (K > 0 && j < RP + K) { // in the LDS ring (separate branches keep ds_read / global_load apart)
                 const int ls = lrec - (j - RP);
@@ -2196,7 +2226,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
                 double h[BF_UNROLL][EPT];
 #pragma unroll
                 for (int u = 0; u < BF_UNROLL; ++u)
-                    if (j + u < n) load_pad<NW, EPT>(H + (size_t)(j + u) * NPAD, h[u]);
+                    if (j + u < n) load_pad_stream<NW, EPT>(H + (size_t)(j + u) * NPAD, h[u]);
 #pragma unroll
                 for (int u = 0; u < BF_UNROLL; ++u) {
                     if (j + u < n) {
@@ -2296,7 +2326,12 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
                         ha = (e == j) ? a_id : 0.0;
                         hb = (e + 1 == j) ? a_id : 0.0;
                     } else {
+#if FL_BFGS_NT >= 2
+                        typedef double fl_d2 __attribute__((ext_vector_type(2)));
+                        const fl_d2 t = __builtin_nontemporal_load(reinterpret_cast<const fl_d2 *>(hp));
+#else
                         const double2 t = *hp;
+#endif
                         ha = t.x;
                         hb = t.y;
                     }
@@ -2306,7 +2341,17 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
                         ha = ha - rq[l][0] * sj - rs[l][0] * qj + cf[l][0] * sj;
                         hb = hb - rq[l][1] * sj - rs[l][1] * qj + cf[l][1] * sj;
                     }
+#if FL_BFGS_NT >= 3
+                    {
+                        typedef double fl_d2s __attribute__((ext_vector_type(2)));
+                        fl_d2s o;
+                        o.x = ha;
+                        o.y = hb;
+                        __builtin_nontemporal_store(o, reinterpret_cast<fl_d2s *>(hp));
+                    }
+#else
                     *hp = make_double2(ha, hb);
+#endif
                 }
             }
         }
