@@ -169,6 +169,7 @@ template <int NW, int EPT> __device__ __forceinline__ void load_pad_nt(const dou
         v[2 * c + 1] = t.y;
     }
 }
+template <int NW, int EPT> __device__ __forceinline__ void store_pad_stream(double *row, const double (&v)[EPT]); // (below store_pad)
 template <int NW, int EPT> __device__ __forceinline__ void load_pad_stream(const double *row, double (&v)[EPT])
 {
 #if FL_BFGS_NT
@@ -191,6 +192,22 @@ template <int NW, int EPT> __device__ __forceinline__ void store_pad(double *row
         for (int c = 0; c < G::NCH; ++c)
             *reinterpret_cast<double2 *>(row + G::e0(c)) = make_double2(v[2 * c], v[2 * c + 1]);
     }
+}
+template <int NW, int EPT> __device__ __forceinline__ void store_pad_stream(double *row, const double (&v)[EPT])
+{
+#if FL_BFGS_NT >= 3
+    using G = Geo<NW, EPT>;
+    typedef double fl_d2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int c = 0; c < G::NCH; ++c) {
+        fl_d2 t;
+        t.x = v[2 * c];
+        t.y = v[2 * c + 1];
+        __builtin_nontemporal_store(t, reinterpret_cast<fl_d2 *>(row + G::e0(c)));
+    }
+#else
+    store_pad<NW, EPT>(row, v);
+#endif
 }
 
 template <int EPT> __device__ __forceinline__ double dot_part(const double (&a)[EPT], const double (&b)[EPT])
@@ -2114,7 +2131,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
                 double h[BF_UNROLL][EPT];
 #pragma unroll
                 for (int u = 0; u < BF_UNROLL; ++u)
-                    if (j + u < n) load_pad<NW, EPT>(H + (size_t)(j + u) * NPAD, h[u]);
+                    if (j + u < n) load_pad_stream<NW, EPT>(H + (size_t)(j + u) * NPAD, h[u]);
 #pragma unroll
                 for (int u = 0; u < BF_UNROLL; ++u) {
                     if (j + u < n) {
@@ -2151,7 +2168,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
                         for (int k = 0; k < EPT; ++k)
                             h[u][k] = (G::e0(k >> 1) + (k & 1) == j + u) ? a : 0.0;
                     } else {
-                        load_pad<NW, EPT>(H + (size_t)(j + u) * NPAD, h[u]);
+                        load_pad_stream<NW, EPT>(H + (size_t)(j + u) * NPAD, h[u]);
                     }
                 }
             }
@@ -2165,7 +2182,7 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
                         h[u][k] = hn;
                         acc[k] = acc[k] + hn * gj;
                     }
-                    store_pad<NW, EPT>(H + (size_t)(j + u) * NPAD, h[u]);
+                    store_pad_stream<NW, EPT>(H + (size_t)(j + u) * NPAD, h[u]);
                 }
             }
         }
