@@ -779,6 +779,14 @@ def compile_check(source, class_name, n, solver=LBFGS_, tune_like=TUNE_NONE, arc
 
 FL.fl_augmented_lagrangian_launch_plan.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
 FL.fl_cooperative_groups_for.argtypes = [C.c_int] * 4
+FL.fl_bfgs_deferred_updates.argtypes = [C.c_int]
+
+
+def bfgs_deferred_updates(n):
+    """rank-2 updates the fused BFGS kernels of dimension n keep pending before folding them into H (0 for n <= 128): the update
+    form of a bit-exact replay (oracle bfgs_form 100 + this, 1 if 0)"""
+    return int(FL.fl_bfgs_deferred_updates(int(n)))
+
 
 
 def cooperative_groups(solver, objective, batch, n):

@@ -563,14 +563,22 @@ template <int NW, int EPT, int OBJ, int METHOD, int AUG, int EXACT = (METHOD == 
     static_assert(REG_PAIRS >= 0 && REG_PAIRS <= 4, "0 .. 4 register pairs");
     // Newton: one row buffer for the Cholesky kernels (BFGS reuses its broadcast arrays)
     static constexpr int L_DEF = L_BF + (METHOD == FL_SOLVER_BFGS ? 3 * NPAD : (METHOD == FL_SOLVER_NEWTON ? NPAD : 0));
-    // BFGS for n > 1024, fused kernels: the rank-2 updates are DEFERRED -- H is left alone for BF_DEFER iterations
+    // BFGS for n > 128 (until round 4: n > 1024), fused kernels: the rank-2 updates are DEFERRED -- H is left alone for BF_DEFER iterations
     // (one read pass per iteration instead of a read pass and a read+write pass), then the pending updates are folded
     // in together (direction_bfgs_deferred).  L_DEF: rho_l, cs_l of the pending updates.
 #ifndef FL_BFGS_DEFER
 #define FL_BFGS_DEFER 8
 #endif
-    static constexpr int BF_DEFER = (METHOD == FL_SOLVER_BFGS && OBJ != FL_OBJ_EXTERNAL && NPAD >= 2048) ? FL_BFGS_DEFER : 0;
-    static constexpr int BF_FOLD_COLS = 128; // columns whose s_l[j], q_l[j] are staged in LDS at a time while folding
+#ifndef FL_BFGS_DEFER_NPAD
+// padded length from which the updates are deferred (also sizes the workspace: fl_workspace_bytes_for; fl_bfgs_deferred_updates tells
+// the caller).  Rounds 2-3: 2048.  Round 4: 256 = every n > 128 -- 20 iterations of 4096 / 8192 / 16 384 problems of n = 1024 / 512 /
+// 256: 385 -> 106 ms, 190 -> 51, 94 -> 26 (the first 8 iterations move no H at all while the identity is implicit; in the steady
+// state 8 n^2 + 16 n^2 / 8 bytes per iteration against 24 n^2: 2.4 x).  Not for n <= 128 (one 1 x 2 wave per problem; the
+// reference's own test problem n = 10: 5.1 -> 6.3 ms with the pending updates' corrections) -- profiles/r04/bfgs_deferral_by_n.txt
+#define FL_BFGS_DEFER_NPAD 256
+#endif
+    static constexpr int BF_DEFER = (METHOD == FL_SOLVER_BFGS && OBJ != FL_OBJ_EXTERNAL && NPAD >= FL_BFGS_DEFER_NPAD) ? FL_BFGS_DEFER : 0;
+    static constexpr int BF_FOLD_COLS = NPAD >= 2048 ? 128 : NPAD / (2 * FL_BFGS_DEFER); // columns whose s_l[j], q_l[j] are staged in LDS at a time while folding
     // SD / CG on the diagonal quadratics at 8 elements per thread (C3: no history, nothing streams from HBM, the trials'
     // latency is all there is): the line search's x0 waits in an LDS row of its own -- one read per trial, every thread
     // reads back what it wrote -- which brings the kernel from 141 to <= 128 VGPRs = 4 waves per SIMD instead of 3

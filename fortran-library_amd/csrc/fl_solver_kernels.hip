@@ -425,7 +425,7 @@ template <int NW, int EPT> static int onchip_pairs_o(int obj)
 
 extern "C" {
 
-int fl_version(void) { return 103; }
+int fl_version(void) { return 104; }
 
 int fl_augmented_lagrangian_launch_plan(int solver, int objective, int batch, int n, int m, int *waves, int *pause_below, int max_stages)
 {
@@ -470,7 +470,7 @@ size_t fl_workspace_bytes_for(int solver, int batch, int n, const fl_options *op
         const size_t npad = (size_t)(g.nw * 64 * g.ept);
         if (solver == FL_SOLVER_NEWTON) return (size_t)batch * (size_t)n * npad * sizeof(double);
         // H (+ Hessian / factor and inverse factor with ExactStep > 0) + the rows of the deferred updates (n > 1024)
-        const size_t defer = npad >= 2048 ? 2 * FL_BFGS_DEFER : 0;
+        const size_t defer = npad >= FL_BFGS_DEFER_NPAD ? 2 * FL_BFGS_DEFER : 0;
         return (size_t)batch * ((size_t)(opt->exact_step > 0 ? 3 : 1) * (size_t)n + defer) * npad * sizeof(double);
     }
     return fl_workspace_bytes(solver, batch, n, opt->memory);
@@ -504,6 +504,16 @@ int fl_reduction_geometry(int n, int *threads, int *ept)
     if (threads) *threads = g.nw * 64;
     if (ept) *ept = g.ept;
     return FL_OK;
+}
+
+// rank-2 updates the fused BFGS kernels of dimension n keep pending before they fold them into H (0: every update is applied at once):
+// the update form a bit-exact replay must use (oracle update_form 100 + this)
+int fl_bfgs_deferred_updates(int n)
+{
+    fl::GeoSel g;
+    if (n <= 0) return 0;
+    if (!fl::select_geometry(n, g)) return n <= fl::BigSolver<FL_OBJ_QUARTIC, FL_SOLVER_BFGS>::BF_MAX_N ? FL_BFGS_DEFER : 0; // vectors in HBM
+    return g.nw * 64 * g.ept >= FL_BFGS_DEFER_NPAD ? FL_BFGS_DEFER : 0;
 }
 
 // workgroups that share one problem in the fused solve of this batch on the current device (1: none; > 1: the cooperative
@@ -545,7 +555,7 @@ size_t fl_workspace_bytes(int solver, int batch, int n, int memory)
         return (size_t)batch * 2 * mem * npad * sizeof(double);
     }
     if (solver == FL_SOLVER_BFGS) // ExactStep <= 0; see fl_workspace_bytes_for
-        return (size_t)batch * ((size_t)n + (npad >= 2048 ? 2 * FL_BFGS_DEFER : 0)) * npad * sizeof(double);
+        return (size_t)batch * ((size_t)n + (npad >= FL_BFGS_DEFER_NPAD ? 2 * FL_BFGS_DEFER : 0)) * npad * sizeof(double);
     return 0;
 }
 

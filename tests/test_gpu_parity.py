@@ -313,8 +313,8 @@ def _oracle_bfgs(kind, x0, d, b, form, mode, kw):
     T, E = NLO.reduction_geometry(n)
     o = _oracle_opts(O.BFGS, kw)
     o.exact_step = kw.get("ExactStep", 0)
-    if form == 1 and T * E >= 2048:  # n > 1024: the kernels defer the rank-2 updates, folding every 8th (form 100 + 8)
-        form = 108
+    if form == 1 and NLO.bfgs_deferred_updates(n):  # n > 128: the kernels defer the rank-2 updates, folding every 8th (form 100 + 8)
+        form = 100 + NLO.bfgs_deferred_updates(n)
     return O.solve_batch(O.BFGS, kind, x0, d=d, b=b, opts=o, use_ffd=bool(kw.get("f_fd", False)), bfgs_form=form,
                          sum_mode=mode, threads=T, ept=E)
 
@@ -579,7 +579,7 @@ def test_augmented_lagrangian_batch_with_the_callers_constraints_by_reverse_comm
     oo = _oracle_opts(solver, kw)
     if solver == O.BFGS:
         oo.exact_step = 0
-        O.lib().flo_set_auglag_bfgs_form(108 if T * E >= 2048 else 1)  # (the rank-2 updates deferred in groups of 8 beyond n = 1024)
+        O.lib().flo_set_auglag_bfgs_form(108 if n > 4096 else 1)  # (by reverse communication only the vectors-in-HBM machine defers its rank-2 updates)
     try:
         o = O.auglag_batch(solver, kind, x0, m, d=d, b=b, opts=oo, sum_mode=O.TREE, threads=T, ept=E)
     finally:
@@ -606,7 +606,7 @@ def test_augmented_lagrangian_batch_with_the_callers_constraints_by_reverse_comm
 def test_augmented_lagrangian_with_bfgs_inner_solver_bitexact(kind, n, m, kw):
     """UnconstrainedSolver = 'BFGS' (NO.f90:2131-2148) with ExactStep = 0: every outer round is a fresh quasi-Newton
     BFGS on the augmented Lagrangian (H rebuilt from a I).  Oracle: flo_augmented_lagrangian around flo_bfgs in the
-    update form the kernels evaluate (rank-2; deferred beyond n = 1024)."""
+    update form the kernels evaluate (rank-2; deferred beyond n = 128)."""
     NLO = _nlo()
     rng = np.random.default_rng(11 * n + m)
     B = 3
@@ -619,7 +619,7 @@ def test_augmented_lagrangian_with_bfgs_inner_solver_bitexact(kind, n, m, kw):
         d, b = _quads(B, n, 2.0, 10.0, 5)
     g = _gpu_auglag("BFGS", kind, x0, m, d, b, ExactStep=0, **kw)
     T, E = NLO.reduction_geometry(n)
-    O.lib().flo_set_auglag_bfgs_form(108 if T * E >= 2048 else 1)
+    O.lib().flo_set_auglag_bfgs_form(100 + NLO.bfgs_deferred_updates(n) if NLO.bfgs_deferred_updates(n) else 1)
     try:
         oo = _oracle_opts(O.BFGS, kw)
         oo.exact_step = 0

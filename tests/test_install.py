@@ -65,11 +65,11 @@ def test_a_c_program_links_the_static_library(prefix, tmp_path):
     subprocess.check_call(["gcc", "-c", f"-I{prefix}/include", str(src), "-o", str(obj)])
     exe = tmp_path / "main_static"
     subprocess.check_call([HIPCC, str(obj), str(prefix / "lib" / "libFL.a"), "-ldl", "-lpthread", "-o", str(exe)])
-    assert subprocess.check_output([str(exe)]).decode().split() == ["103", "10", "128", "8"]
+    assert subprocess.check_output([str(exe)]).decode().split() == ["104", "10", "128", "8"]
 
 
 def test_the_installed_python_package_finds_the_installed_library(prefix):
     code = ("import sys; sys.path.insert(0, %r); import FortranLibrary.basic as B; import FortranLibrary.NonlinearOptimization as N; "
             "assert B.library_path().startswith(%r), B.library_path(); print(N.FL.fl_version())" % (str(prefix), str(prefix)))
     env = {k: v for k, v in os.environ.items() if k not in ("FL_LIBRARY", "PYTHONPATH")}
-    assert subprocess.check_output([sys.executable, "-c", code], env=env).decode().strip() == "103"
+    assert subprocess.check_output([sys.executable, "-c", code], env=env).decode().strip() == "104"
