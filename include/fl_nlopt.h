@@ -121,8 +121,9 @@ int fl_reduction_geometry_for(int solver, int n, int *threads, int *ept);
 /* The fused BFGS kernels (fl_bfgs_batched, BFGS inside fl_augmented_lagrangian_batched) apply their rank-2 updates DEFERRED for
  * n > 128: H is left alone for 8 iterations, the product H g is corrected with the pending updates' vectors, and every 8th
  * iteration they are folded into H in the order they occurred -- algebraically the reference's update (NO.f90:958-962), a third of
- * its HBM traffic.  Returns how many updates stay pending for dimension n (0 = each is applied at once: n <= 128, and always by
- * reverse communication).  A bit-exact replay needs it (oracle update_form 100 + this). */
+ * its HBM traffic.  Returns how many updates stay pending for dimension n (0 = each is applied at once: n <= 128, and by reverse
+ * communication up to n = 4096 -- there H's bytes are a small part of a step and the deferred form measured slower).  A bit-exact
+ * replay needs it (oracle update_form 100 + this). */
 int fl_bfgs_deferred_updates(int n);
 /* FEW problems of very large n (the reference's callers typically solve ONE problem of any dim): beyond n = 14336 and below one
  * problem per two compute units, fl_steepest_descent_batched / fl_conjugate_gradient_batched / fl_lbfgs_batched (objectives
