@@ -146,7 +146,8 @@ int fl_lbfgs_onchip_pairs(int objective, int n);
 
 /* Bytes of device workspace: FL_SOLVER_LBFGS -- the (s,y) history ring,
  * [batch][2*memory][padded n] fp64 (n > 4096: plus four vector rows per problem);
- * FL_SOLVER_BFGS -- the inverse Hessians [batch][n][padded n]; 0 for SD / CG (n > 4096: their four
+ * FL_SOLVER_BFGS -- the inverse Hessians [batch][n][padded n] plus, for n > 128, 16 rows per problem for the vectors of the
+ * pending updates (fl_bfgs_deferred_updates); 0 for SD / CG (n > 4096: their four
  * vector rows come from the stream-ordered allocator inside the call). */
 size_t fl_workspace_bytes(int solver, int batch, int n, int memory);
 /* the same from an option block: BFGS with exact_step > 0 needs three matrices per problem (inverse
