@@ -206,3 +206,17 @@ def test_augmented_lagrangian_launch_plan_by_batch():
         assert P(NLO.LBFGS_, NLO.DIAGQUAD, 8192, 512, 8) == [(1, 0)] and P(NLO.LBFGS_, NLO.DIAGQUAD, 1024, 512, 8) == [(2, 0)]
     finally:
         del os.environ["FL_AUG_STAGED"]
+
+
+def test_update_form_and_cooperative_queries_answer_without_a_device():
+    """fl_bfgs_deferred_updates: the fused BFGS kernels keep 8 rank-2 updates pending for n > 128 (also beyond the register path, up
+    to the dense H's n = 16384), none for n <= 128; fl_cooperative_groups_for: 1 where no device answers (the cooperative form
+    needs the CU count) and for everything that never shares a problem"""
+    lib = C.CDLL(os.path.join(ROOT, "fortran-library_amd", "lib", "libFL.so"))
+    f = lib.fl_bfgs_deferred_updates
+    f.argtypes = [C.c_int]
+    assert [f(n) for n in (0, 1, 10, 128, 129, 256, 1024, 4096, 4097, 16384, 16385)] == [0, 0, 0, 0, 8, 8, 8, 8, 8, 8, 0]
+    g = lib.fl_cooperative_groups_for
+    g.argtypes = [C.c_int] * 4
+    assert g(2, 2, 1, 1 << 20) >= 1      # (1 here: no GPU in the CPU test container; > 1 on a device)
+    assert g(2, 2, 1, 4096) == 1 and g(3, 2, 1, 16000) == 1 and g(2, 1, 1, 1 << 20) == 1 and g(2, 2, 0, 1 << 20) == 1
