@@ -952,6 +952,59 @@ def rtc_leg(ctx, NLO):
             "same_bits_as_builtin": same, "note": "timed with the memset of x inside (both legs alike)"}
 
 
+def bfgs_mid_leg(ctx, NLO, cpu_seconds):
+    """BFGS -- the reference's DEFAULT solver (NO.f90:632-1022) -- at a size its users have: n = 1024, 4096 problems, ExactStep = 0,
+    a fixed 20 iterations like BASELINE config 4.  Since round 4 the fused kernels keep 8 rank-2 updates pending and fold them
+    into H every 8th iteration for every n > 128 (fl_bfgs_deferred_updates): 10 n^2 bytes per iteration in the steady state where
+    the update applied at once moves 24 n^2.  Parity: the oracle's deferred form in the kernel's summation order, bit for bit."""
+    import numpy as np
+    torch = ctx.torch
+    B, n, K = 4096, 1024, 20
+    d, b = _quad(ctx, NLO, B, n, 10.0, 100.0)
+    x = torch.zeros(B, n, dtype=torch.float64, device=ctx.dev)
+    ws = NLO.bfgs_workspace(B, n, ctx.dev)
+    kw = dict(Precision=1e-12, MaxIteration=K - 1, ExactStep=0)
+
+    def run():
+        x.zero_()
+        return NLO.BFGS(NLO.DIAGQUAD, x, d, b, workspace_=ws, **kw)
+    out, ms = timed_launches(ctx, run, 3)
+    it = out["iters"].to(torch.int64)
+    upd = torch.clamp(it - 1, min=0)
+    J = NLO.bfgs_deferred_updates(n)
+    folds = torch.div(upd, J, rounding_mode="floor")
+    moved = float((torch.clamp(upd - J, min=0) * 8 * n * n + (folds > 0) * 8 * n * n + torch.clamp(folds - 1, min=0) * 16 * n * n).sum())
+    algo = float((upd * 24 * n * n + (it > 0) * 8 * n * n).sum())
+    r = {"workload": f"BFGS (ExactStep=0), diagonal quadratics n={n}, kappa in [10,100], batch {B}, a fixed {K} iterations",
+         "ms": ms, "iterations_per_s": float(it.sum()) / ms * 1e3, "updates_kept_pending": J,
+         "roofline": {"bound": "hbm", "kernel": "fl_solve_kernel<2,8,DIAGQUAD,BFGS,0,0>", "achieved": moved / ms / 1e6, "peak": HBM_PEAK_GBS,
+                      "unit": "GB/s", "frac": moved / ms / 1e6 / HBM_PEAK_GBS, "traffic": None, "achieved_source": "byte model of the deferred rank-2 form",
+                      "algorithmic_bytes_per_launch": algo, "algorithmic_bw": algo / ms / 1e6,
+                      "note": "algorithmic = 24 n^2 B per update of the form applied at once (rounds 1-3 at this n: 385 ms)"}}
+    if cpu_seconds > 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        Bc = 2 * ctx.cores
+        oo = O.defaults(precision=1e-12, maxit=K - 1, exact_step=0)
+        dh, bh = d[:Bc].cpu().numpy(), b[:Bc].cpu().numpy()
+        t = time.perf_counter()
+        ref = O.solve_batch(O.BFGS, O.DIAGQUAD, np.zeros((Bc, n)), d=dh, b=bh, opts=oo, bfgs_form=1, nthreads=ctx.cores)
+        dt = time.perf_counter() - t
+        r["cpu_baseline"] = {"value": float(ref["iters"].sum()) / dt, "unit": "iterations/s", "cores": int(ref["threads"]), "kind": "port",
+                             "sample": f"first {Bc} problems, oracle in the O(n^2) rank-2 form, reference summation order, {dt:.2f} s wall"}
+        T, E = NLO.reduction_geometry(n)
+        SB = 8
+        tre = O.solve_batch(O.BFGS, O.DIAGQUAD, np.zeros((SB, n)), d=dh[:SB], b=bh[:SB], opts=oo, bfgs_form=100 + J, sum_mode=O.TREE, threads=T,
+                            ept=E, nthreads=ctx.cores)
+        fmax, _ = _f_parity(out["f"][:Bc].cpu().numpy(), ref["f"], 1e-300)
+        bit = {"problems": SB, "x": bits_equal(x[:SB].cpu().numpy(), tre["x"]), "f": bits_equal(out["f"][:SB].cpu().numpy(), tre["f"]),
+               "iterations": bits_equal(out["iters"][:SB].cpu().numpy(), tre["iters"])}
+        r["parity"] = {"final_f_rel_err_max_vs_reference_order": fmax, "bit_exact_vs_oracle_kernel_order": bit,
+                       "ok": bool(fmax <= 1e-10 and bit["x"] and bit["f"] and bit["iterations"])}
+        r["speedup_vs_cpu_baseline"] = r["iterations_per_s"] / r["cpu_baseline"]["value"]
+    return r
+
+
 def one_problem_leg(ctx, NLO, cpu_seconds):
     """The reference's typical call -- ONE problem (LBFGS takes one x: NO.f90:398-625) -- at n = 2^20: the fused solve shares the
     problem among `groups` workgroups (csrc/fl_big.hpp, the cooperative form: one launch, a trial at many CUs' bandwidth plus a
@@ -1117,6 +1170,7 @@ def main():
     if names and ctx.world == 1 and ctx.rank == 0:
         res["user_objective_compiled_at_run_time"] = rtc_leg(ctx, NLO)
         res["one_problem_of_a_million_unknowns"] = one_problem_leg(ctx, NLO, args.config_cpu_seconds)
+        res["bfgs_default_solver_n1024"] = bfgs_mid_leg(ctx, NLO, args.config_cpu_seconds)
 
     bad = False
     if ctx.rank == 0:
