@@ -1029,8 +1029,13 @@ template <int OBJ, int METHOD, int AUG = 0> struct BigSolver {
         double *H = hist, *stage = lds + L_STAGE;
         const double *drho = lds + L_RHO, *dcs = drho + J;
         __syncthreads();
+        // (one element per thread and sweep, CONTIGUOUS across the workgroup -- e = c2 * 1024 + tid, not the pair layout of the
+        //  vector passes: a sweep over a column then touches whole 64-byte lines once instead of half of each in two sweeps.  Any
+        //  thread may fold any element: the barriers at both ends of the fold separate it from the passes that own their pairs)
         for (int c2 = 0; c2 < 2 * nslot; ++c2) {
-            const int e = e_of(c2 >> 1) + (c2 & 1);
+            int tl_ = tid;
+            asm volatile("" : "+v"(tl_));
+            const int e = c2 * T + tl_;
             double rq[J], rs[J], cf[J];
 #pragma unroll
             for (int l = 0; l < J; ++l) {
