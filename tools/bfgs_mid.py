@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.join(ROOT, "fortran-library_amd")); sys.path.insert(0
 import ctypes as C
 import FortranLibrary.NonlinearOptimization as NLO
 dev = torch.device("cuda:0")
-for n, B in ((1024, 4096), (512, 8192), (256, 16384), (128, 32768), (64, 65536), (10, 65536))[:int(os.environ.get("BFGS_MID_CASES", "6"))]:
+SIZES = [tuple(int(v) for v in s.split("x")) for s in os.environ["BFGS_MID_SIZES"].split(",")] if "BFGS_MID_SIZES" in os.environ else ((1024, 4096), (512, 8192), (256, 16384), (128, 32768), (64, 65536), (10, 65536))
+for n, B in SIZES[:int(os.environ.get("BFGS_MID_CASES", "6"))]:
     d = torch.empty(B, n, dtype=torch.float64, device=dev); b = torch.empty_like(d)
     NLO.synth_diag_spectrum(7, d, 10.0, 100.0); NLO.synth_uniform(7, b, -1.0, 1.0)
     x = torch.zeros(B, n, dtype=torch.float64, device=dev)
